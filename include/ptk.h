@@ -1,0 +1,154 @@
+/* ptk — "path-trace kernels": the C-ABI drop-in boundary of the MI355X render path.
+ *
+ * This is what a binding in the reference application would call instead of the body of
+ * PathTracer::RenderFrame() and friends (reference PathTracing/src/pathtracer.h:100-130,
+ * pathtracer.cpp:260-365, :741-822).  Plain C: opaque context, plain pointers and sizes, int status
+ * codes; no C++/torch types cross it.  One context drives one GPU on one HIP stream.
+ *
+ * Call order (mirrors the reference's LoadObject / Set... -> BuildBVH -> SetResolution -> SetOutImage ->
+ * ResetImage -> RenderFrame()xN contract):
+ *   ptk_create -> ptk_upload_scene -> ptk_set_camera -> ptk_set_frame -> ptk_reset ->
+ *   ptk_render(first, n, seed) ... -> ptk_resolve_rgb8 / ptk_read_accum -> ptk_destroy
+ *
+ * Every function returns PTK_OK (0) or a negative error class; ptk_last_error() gives the text.
+ * Nothing throws across this boundary.  Host pointers are borrowed for the duration of the call.
+ */
+#ifndef PTK_H
+#define PTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTK_OK 0
+#define PTK_ERR_BAD_ARG (-1)     /* null / out-of-range argument, call-order violation */
+#define PTK_ERR_HIP (-2)         /* a HIP runtime call failed (no device, out of memory, ...) */
+#define PTK_ERR_RCCL (-3)        /* an RCCL call failed */
+#define PTK_ERR_LIMIT (-4)       /* scene exceeds a kernel limit (BVH depth, index width) */
+
+#define PTK_TILE 16              /* pixel tile edge: one 256-thread block = one 16x16 tile */
+#define PTK_MAX_BVH_DEPTH 32     /* entries of the per-lane LDS traversal stack */
+
+/* replaces Material (mesh.h:21-59) with texture *indices* instead of Image pointers */
+typedef struct {
+    int32_t type;                /* 0 OPAQUE, 1 TRANSLUCENT (mesh.h:15-19) */
+    float diffuse[3];
+    float specular[3];
+    float emissive[3];
+    float emissive_intensity;
+    float roughness;
+    float reflectiveness;
+    float translucency;
+    float ior;
+    int32_t tex[6];              /* diffuse, normal, emissive, roughness, metallic, opacity; -1 = none */
+} ptk_material;                  /* 84 bytes, packed the same as the natural layout */
+
+/* replaces Image (image.h:7-28): RGBA8 texels live in one atlas */
+typedef struct {
+    int32_t width, height;
+    int64_t offset;              /* byte offset of this image's first texel in `texels` */
+} ptk_texture;
+
+/* replaces std::vector<Triangle> mTriangles + mLoadedObjects materials + mLights
+ * (pathtracer.h:51-56; Triangle = mesh.h:71-96) as flat arrays */
+typedef struct {
+    int32_t num_triangles;
+    const float* verts;          /* [N][9]  v1 v2 v3, world space */
+    const float* normals;        /* [N][9]  n1 n2 n3 */
+    const float* uvs;            /* [N][6]  uv1 uv2 uv3 */
+    const float* tbn;            /* [N][9]  normal, tangent, bitangent (Triangle::Init, mesh.cpp:61-83) */
+    const uint8_t* smoothing;    /* [N] */
+    const int32_t* material;     /* [N] index into materials */
+    int32_t num_materials;
+    const ptk_material* materials;
+    int32_t num_textures;
+    const ptk_texture* textures;
+    const uint8_t* texels;
+    int64_t texel_bytes;
+    int32_t num_lights;
+    const int32_t* lights;       /* triangles whose material has |emissive| >= 1e-5 (pathtracer.cpp:267-273) */
+} ptk_scene_desc;
+
+/* traversal statistics from the counters-enabled (untimed) kernel variant; feeds the
+ * algorithmic-bytes roofline of SURVEY.md §8(d4) */
+typedef struct {
+    uint64_t samples;            /* pixel*spp processed */
+    uint64_t rays;               /* closest-hit traversals (bounce + shadow rays) */
+    uint64_t shadow_rays;
+    uint64_t node_visits;        /* 64-byte BVH node records fetched */
+    uint64_t tri_tests;          /* 48-byte triangle records fetched */
+    uint64_t hits_shaded;        /* surface interactions shaded */
+    uint64_t tex_fetches;        /* 4-byte texel fetches */
+} ptk_stats;
+
+typedef struct ptk_ctx ptk_ctx;
+
+/* ctor/dtor of the device side of PathTracer (pathtracer.cpp:11-39) */
+int  ptk_create(ptk_ctx** out, int device_ordinal);
+void ptk_destroy(ptk_ctx* ctx);
+
+/* replaces BuildBVH (pathtracer.cpp:260-274, mesh.cpp:169-211): stages the scene, builds the
+ * device BVH (own builder; closest hit is tree-independent) and uploads everything to HBM */
+int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene);
+
+/* SetCamera + SetProjection + SetCameraFocalDist + SetCameraAperture (pathtracer.cpp:333-360).
+ * dir/up are normalised and focal/fovy clamped exactly as the reference setters do. */
+int ptk_set_camera(ptk_ctx* ctx, const float pos[3], const float dir[3], const float up[3],
+                   float focal, float fovy_deg, float focal_dist, float aperture);
+
+/* SetResolution + SetTraceDepth (pathtracer.cpp:302-306, :328-331); (re)allocates the float
+ * accumulator (mTotalImg) and the RGB8 image on the device */
+int ptk_set_frame(ptk_ctx* ctx, int width, int height, int max_depth);
+
+/* multi-GPU: this context renders only the 16x16 pixel tiles t with t % world == rank */
+int ptk_set_tile(ptk_ctx* ctx, int rank, int world);
+
+/* ResetImage (pathtracer.cpp:276-279, :745-751): zero the accumulator and the sample count */
+int ptk_reset(ptk_ctx* ctx);
+
+/* RenderFrame (pathtracer.cpp:741-817) x spp_count: adds samples [first_sample, first_sample +
+ * spp_count) to every owned pixel and refreshes the device RGB8 image.  Asynchronous on the
+ * context's stream.  The RNG is keyed on (seed, pixel, sample index): results do not depend on how
+ * samples are batched into calls or on the GPU count. */
+int ptk_render(ptk_ctx* ctx, uint32_t first_sample, uint32_t spp_count, uint64_t seed);
+
+/* the host-buffer hand-off of mOutImg (pathtracer.cpp:802-812, main.cpp:3026-3029):
+ * W*H*3 bytes, RGB, rows bottom-up, tightly packed; waits for the stream */
+int ptk_resolve_rgb8(ptk_ctx* ctx, uint8_t* host_out);
+/* mTotalImg: W*H*3 floats, rows bottom-up; waits for the stream */
+int ptk_read_accum(ptk_ctx* ctx, float* host_out);
+int ptk_write_accum(ptk_ctx* ctx, const float* host_in, int samples);   /* resume from a saved accumulator */
+
+int ptk_samples(ptk_ctx* ctx);         /* GetSamples (pathtracer.cpp:362-365); thread-safe */
+int ptk_request_exit(ptk_ctx* ctx);    /* Exit (pathtracer.cpp:819-822); thread-safe; skips work not yet started */
+int ptk_synchronize(ptk_ctx* ctx);
+const char* ptk_last_error(ptk_ctx* ctx);
+
+/* device-resident hand-off (no host copy): the accumulator's device address, for a caller that
+ * gathers it with its own collective (torch.distributed / RCCL) or maps it into a GL texture */
+int ptk_accum_device_ptr(ptk_ctx* ctx, void** dev_ptr, size_t* bytes);
+int ptk_rgb8_device_ptr(ptk_ctx* ctx, void** dev_ptr, size_t* bytes);
+/* render into a caller-owned device accumulator (W*H*3 floats) instead of the internal one */
+int ptk_bind_accum(ptk_ctx* ctx, void* dev_ptr);
+int ptk_set_stream(ptk_ctx* ctx, void* hip_stream);
+
+/* multi-GPU exchange step: sum-reduce the float accumulator to `root` over an RCCL communicator
+ * (ncclComm_t passed as void*); tiles a rank does not own are zero, so the sum is a gather */
+int ptk_gather_accum(ptk_ctx* ctx, void* rccl_comm, int root);
+
+/* measurement */
+int ptk_last_render_ms(ptk_ctx* ctx, float* ms, int* launches);  /* HIP-event time of the last ptk_render's kernels */
+int ptk_collect_stats(ptk_ctx* ctx, uint32_t first_sample, uint32_t spp_count, uint64_t seed, ptk_stats* out);
+int ptk_bvh_info(ptk_ctx* ctx, int32_t* num_nodes, int32_t* depth, int32_t* num_leaf_tris);
+
+/* probes used by the parity tests (same semantics as the kernels' device functions) */
+int ptk_probe_hits(ptk_ctx* ctx, int n, const float* ro, const float* rd, int32_t* tri, float* tuv);
+int ptk_probe_primary_dirs(ptk_ctx* ctx, float* host_out /* [H][W][3] top-down */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

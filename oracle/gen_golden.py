@@ -1,0 +1,315 @@
+"""TEST INFRASTRUCTURE ONLY — generates the committed golden vectors under tests/golden/ from the
+REAL reference (oracle/_ref/libptref.so, built from /root/reference by oracle/Makefile.ref).
+
+    make -f oracle/Makefile.ref && python -m oracle.gen_golden
+
+The reference ships no tests, fixtures or assets, so every vector is produced here by
+driving the reference's own code on synthetic inputs:
+  tier K  per-function known answers  (IntersectTriangle, AABB, Triangle::Init, Image::tex2D,
+          SampleCircle, DirectIllumimation, Hit, glm TRS / Euler camera, LoadObject staging)
+  tier T  draw-tape paths: mRng seeded, Trace run single-threaded, the float draws it consumed and
+          the radiance it returned
+  tier S  converged mean images (RenderFrame, OpenMP, as shipped)
+A fixture is data only (inputs + expected outputs); no reference text is stored.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from pbrpathtracer_amd import scenes as S  # noqa: E402
+from oracle.ref_binding import Ref, _fp  # noqa: E402
+from oracle.ref_scene import arrays_from_ref  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SCENE_KEYS = ("verts", "normals", "uvs", "tbn", "smoothing", "material", "materials", "textures", "texels", "lights")
+
+
+def save(name, **kw):
+    os.makedirs(GOLD, exist_ok=True)
+    p = os.path.join(GOLD, name)
+    np.savez_compressed(p, **kw)
+    print("wrote", p, os.path.getsize(p) // 1024, "KiB")
+
+
+# --------------------------------------------------------------------------------------------
+# micro scenes for tier T / S (small enough to commit their flat arrays)
+
+
+def micro_scene(kind: str, out_dir: str) -> S.SceneDesc:
+    sc = S.SceneDesc(trace_depth=4, width=64, height=64, focal_dist=3.5, camera_f=1.0e9)
+    groups, mats = S.cornell_groups(uv=True)
+    tex = {}
+
+    def T(name, img):
+        p = os.path.join(out_dir, name + ".ppm")
+        S.write_ppm(p, img)
+        tex[name] = p
+        return p
+
+    if kind == "cornell":
+        pass
+    elif kind == "glossy":
+        # every OPAQUE sampler branch: roughness 1 / 0 / in-between, smooth and flat normals
+        specs = [(-0.55, 1.0, 0.6), (0.0, 0.0, 0.9), (0.55, 0.35, 0.7)]
+        for k, (x, rough, refl) in enumerate(specs):
+            groups.append(S.uv_sphere(f"ball{k}", (x, -0.6, 0.1 * k), 0.33, 12, 8, smooth=(k != 1)))
+            mats.append(S.MaterialDesc(diffuse=(0.8, 0.6, 0.3), specular=(0.9, 0.9, 0.8), roughness=rough,
+                                       reflectiveness=refl))
+        mats[0] = S.MaterialDesc(diffuse=(0.7, 0.7, 0.7), roughness=0.2, reflectiveness=0.5)  # glossy floor
+    elif kind == "glass":
+        specs = [(-0.5, 0.0, 0.0, 1.0, 1.5), (0.0, 0.3, 0.1, 0.8, 1.33), (0.55, 1.0, 0.3, 0.5, 1.7)]
+        for k, (x, rough, refl, transl, ior) in enumerate(specs):
+            groups.append(S.uv_sphere(f"glass{k}", (x, -0.55, -0.1), 0.36, 12, 8, smooth=True))
+            mats.append(S.MaterialDesc(type=S.TRANSLUCENT, diffuse=(0.95, 0.9, 0.85), specular=(1.0, 0.95, 0.9),
+                                       roughness=rough, reflectiveness=refl, translucency=transl, ior=ior))
+    elif kind in ("textured", "opacity"):
+        chk = T("chk", S.tex_checker(32, 4))
+        nrm = T("nrm", S.tex_normal_waves(32, 2, 0.8))
+        rgh = T("rgh", S.tex_noise(32, 11, 0, 255, 4))
+        mtl = T("mtl", S.tex_noise(32, 12, 0, 255, 8))
+        ems = T("ems", (S.tex_dots(32, 4, 0.3) // 4).astype(np.uint8))
+        mats[0].textures["diffuse"] = chk          # floor: checker albedo
+        mats[2].textures["normal"] = nrm           # back wall: normal map
+        mats[3].textures["emissive"] = ems         # left wall: emissive texture (creates no light)
+        groups.append(S.uv_sphere("tball0", (-0.45, -0.55, 0.0), 0.4, 12, 8, smooth=True))
+        m0 = S.MaterialDesc(diffuse=(0.9, 0.9, 0.9), roughness=0.5, reflectiveness=0.5)
+        m0.textures.update({"roughness": rgh, "metallic": mtl, "normal": nrm, "diffuse": chk})
+        mats.append(m0)
+        groups.append(S.uv_sphere("tball1", (0.5, -0.55, -0.2), 0.4, 12, 8, smooth=False))
+        m1 = S.MaterialDesc(diffuse=(0.3, 0.5, 0.9), roughness=1.0, reflectiveness=0.0)
+        if kind == "opacity":
+            m1.textures["opacity"] = T("opa", S.tex_dots(32, 4, 0.35))
+            sc.camera_f = 2.0       # thin lens: aperture 0.025
+            sc.focal_dist = 3.2
+        mats.append(m1)
+    else:
+        raise ValueError(kind)
+    obj = os.path.join(out_dir, kind + ".obj")
+    S.write_obj(obj, groups)
+    sc.objects.append(S.ObjectDesc(obj, kind, [S.ElementDesc(g.name, m) for g, m in zip(groups, mats)]))
+    return sc
+
+
+def scene_arrays_dict(arr):
+    return {"scene_" + k: arr[k] for k in SCENE_KEYS}
+
+
+def camera_dict(ref):
+    cam = np.zeros(9, np.float32); proj = np.zeros(2, np.float32)
+    ref.lib.ref_get_camera(_fp(cam)); ref.lib.ref_get_projection(_fp(proj))
+    return cam, proj
+
+
+# --------------------------------------------------------------------------------------------
+
+
+def tier_k(ref: Ref, tmp: str):
+    rng = np.random.default_rng(20240607)
+    L = ref.lib
+    # IntersectTriangle -----------------------------------------------------------------------
+    n = 1200
+    ro = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    v = rng.uniform(-1.5, 1.5, (n, 3, 3)).astype(np.float32)
+    target = (v * rng.dirichlet([1, 1, 1], n)[..., None].astype(np.float32)).sum(1)
+    rd = target - ro
+    rd[: n // 2] += rng.normal(0, 0.6, (n // 2, 3)).astype(np.float32)     # half of them mostly miss
+    rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    # edge cases: parallel ray, tiny determinant, hit behind origin, hits through a vertex / an edge
+    extra_ro, extra_rd, extra_v = [], [], []
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    for o, d in [((0.2, 0.2, 1), (1, 0, 0)), ((0.2, 0.2, 1), (0, 0, -1)), ((0.2, 0.2, -1), (0, 0, -1)),
+                 ((0, 0, 1), (0, 0, -1)), ((0.5, 0.5, 1), (0, 0, -1)), ((0.5, 0, 1), (0, 0, -1)),
+                 ((0.2, 0.2, 1e-6), (0, 0, -1)), ((0.2, 0.2, 2e-5), (0, 0, -1)), ((1, 1, 1), (0, 0, -1)),
+                 ((0.25, 0.25, 1), (1e-6, 0, -1))]:
+        extra_ro.append(o); extra_rd.append(d); extra_v.append(tri)
+    small = tri * 1e-3                                   # |a| < EPS cull (scale dependent)
+    extra_ro.append((2e-4, 2e-4, 1)); extra_rd.append((0, 0, -1)); extra_v.append(small)
+    ro = np.concatenate([ro, np.array(extra_ro, np.float32)])
+    rd = np.concatenate([rd, np.array(extra_rd, np.float32)])
+    v = np.concatenate([v, np.array(extra_v, np.float32)])
+    out = np.zeros((len(ro), 3), np.float32)
+    for i in range(len(ro)):
+        L.ref_intersect_triangle(_fp(ro[i]), _fp(rd[i]), _fp(v[i, 0].copy()), _fp(v[i, 1].copy()), _fp(v[i, 2].copy()), _fp(out[i]))
+    k = dict(it_ro=ro, it_rd=rd, it_v=v, it_out=out)
+
+    # AABB::Intersect truth table (incl. zero direction components, box behind the ray) -----------
+    n = 400
+    bmin = rng.uniform(-1, 0, (n, 3)).astype(np.float32)
+    bmax = (bmin + rng.uniform(0.1, 1.5, (n, 3))).astype(np.float32)
+    bro = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    brd = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    brd[::7, 0] = 0.0; brd[::11, 1] = 0.0; brd[::13, 2] = 0.0
+    brd = (brd / np.linalg.norm(brd, axis=1, keepdims=True)).astype(np.float32)
+    bout = np.array([L.ref_aabb_intersect(_fp(bmin[i]), _fp(bmax[i]), _fp(bro[i]), _fp(brd[i])) for i in range(n)], np.int32)
+    k.update(bb_min=bmin, bb_max=bmax, bb_ro=bro, bb_rd=brd, bb_out=bout)
+    # AABB::Build + Check on flat triangles
+    pts = rng.uniform(-1, 1, (64, 3, 3)).astype(np.float32)
+    pts[::2, :, 1] = pts[::2, 0:1, 1]                       # axis-aligned (zero thickness in y)
+    bo = np.zeros((64, 6), np.float32)
+    for i in range(64):
+        L.ref_aabb_build(_fp(pts[i].copy()), 3, _fp(bo[i]))
+    k.update(ab_pts=pts, ab_out=bo)
+
+    # Triangle::Init (TBN) --------------------------------------------------------------------------
+    n = 200
+    tin = np.concatenate([rng.uniform(-1, 1, (n, 9)), rng.uniform(0, 1, (n, 6))], axis=1).astype(np.float32)
+    tin[:8, 9:] = 0.0                                        # no uvs -> inf/NaN tangents
+    tout = np.zeros((n, 9), np.float32)
+    for i in range(n):
+        L.ref_triangle_init(_fp(tin[i]), _fp(tout[i]))
+    k.update(ti_in=tin, ti_out=tout)
+
+    # Image::tex2D on a 7x5 image -------------------------------------------------------------------
+    img = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    p = os.path.join(tmp, "t75.ppm"); S.write_ppm(p, img)
+    w = C.c_int(); h = C.c_int()
+    assert L.ref_image_load(p.encode(), C.byref(w), C.byref(h)) == 1
+    rgba = np.zeros((5, 7, 4), np.uint8); L.ref_image_data(rgba.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    uv = np.concatenate([rng.uniform(-2.5, 2.5, (300, 2)),
+                         np.array([[0, 0], [0.999999, 0.999999], [1, 1], [-1, -1], [0.5, 0.5], [-0.25, 1.75],
+                                   [3.0, -3.0], [1e-7, 1e-7], [0.142857, 0.2], [0.1428572, 0.2000001]])]).astype(np.float32)
+    tout4 = np.zeros((len(uv), 4), np.float32)
+    for i in range(len(uv)):
+        L.ref_tex2d(float(uv[i, 0]), float(uv[i, 1]), _fp(tout4[i]))
+    k.update(tx_rgba=rgba, tx_uv=uv, tx_out=tout4)
+    # Image::Load downscale rule (>1024 -> longest side 1024); only the resulting size is pinned
+    big = rng.integers(0, 256, (300, 1500, 3), dtype=np.uint8)
+    p = os.path.join(tmp, "big.ppm"); S.write_ppm(p, big)
+    L.ref_image_load(p.encode(), C.byref(w), C.byref(h))
+    k.update(tx_big_in=np.array([1500, 300], np.int32), tx_big_out=np.array([w.value, h.value], np.int32))
+
+    # SampleCircle (2 draws: angle, radius) ----------------------------------------------------------
+    n = 256
+    sc_tape = np.zeros((n, 2), np.float32); sc_out = np.zeros((n, 2), np.float32)
+    for i in range(n):
+        L.ref_seed(5000 + i)
+        sc_tape[i] = ref.peek_tape(2)
+        L.ref_sample_circle(_fp(sc_out[i]))
+    k.update(sc_tape=sc_tape, sc_out=sc_out)
+
+    # glm 0.9.3.1 TRS (degrees) and Euler camera -------------------------------------------------------
+    n = 64
+    loc = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    rot = rng.uniform(-360, 360, (n, 3)).astype(np.float32)
+    scl = rng.uniform(0.2, 3, (n, 3)).astype(np.float32)
+    rot[0] = 0; loc[0] = 0; scl[0] = 1
+    rot[1] = (90, 0, 0); rot[2] = (0, 90, 0); rot[3] = (0, 0, 90)
+    M = np.zeros((n, 16), np.float32); cam = np.zeros((n, 6), np.float32)
+    for i in range(n):
+        L.ref_trs_matrix(_fp(loc[i]), _fp(rot[i]), _fp(scl[i]), _fp(M[i]))
+        L.ref_euler_camera(_fp(rot[i]), _fp(cam[i]))
+    k.update(trs_loc=loc, trs_rot=rot, trs_scl=scl, trs_out=M, euler_out=cam)
+    save("tier_k.npz", **k)
+
+
+def tier_k_scene(ref: Ref, tmp: str):
+    """LoadObject staging (pathtracer.cpp:41-145) + Hit + DirectIllumimation on a staged scene."""
+    rng = np.random.default_rng(99)
+    sc = micro_scene("glossy", tmp)
+    sc.objects[0].location = (0.05, -0.02, 0.1)
+    sc.objects[0].rotation = (3.0, -7.0, 2.0)
+    sc.objects[0].scale = (1.0, 1.1, 0.9)
+    ref.load_scene(sc)
+    arr = arrays_from_ref(ref, sc)
+    with open(sc.objects[0].obj_path, "rb") as f:
+        obj_bytes = np.frombuffer(f.read(), np.uint8)
+    M = np.zeros(16, np.float32)
+    ref.lib.ref_trs_matrix(_fp(np.array(sc.objects[0].location, np.float32)), _fp(np.array(sc.objects[0].rotation, np.float32)),
+                           _fp(np.array(sc.objects[0].scale, np.float32)), _fp(M))
+    # Hit: closest hit through the reference's recursive walk; irrational offsets avoid exact ties
+    n = 1500
+    ro = np.tile(np.array([0.0123, -0.0456, -3.5], np.float32), (n, 1))
+    ro[n // 2:] = rng.uniform(-0.8, 0.8, (n - n // 2, 3)).astype(np.float32)
+    rd = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    rd[: n // 2] = np.stack([rng.uniform(-.5, .5, n // 2), rng.uniform(-.5, .5, n // 2), np.ones(n // 2)], 1)
+    rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    tri = np.zeros(n, np.int32); tuv = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        h, t, o = ref.hit(ro[i], rd[i])
+        tri[i] = t; tuv[i] = o
+    # DirectIllumimation with tape (3 draws)
+    m = 300
+    p = rng.uniform(-0.9, 0.9, (m, 3)).astype(np.float32)
+    nn = rng.normal(0, 1, (m, 3)).astype(np.float32); nn = (nn / np.linalg.norm(nn, axis=1, keepdims=True)).astype(np.float32)
+    dif = rng.uniform(0, 1, (m, 3)).astype(np.float32)
+    tape = np.zeros((m, 3), np.float32); out = np.zeros((m, 3), np.float32)
+    for i in range(m):
+        ref.lib.ref_seed(9000 + i)
+        tape[i] = ref.peek_tape(3)
+        ref.lib.ref_direct_illumination(_fp(rd[i]), _fp(p[i]), _fp(nn[i]), _fp(dif[i]), _fp(out[i]))
+    save("tier_k_scene.npz", obj_file=obj_bytes, model=M, n_elements=np.int32(len(sc.objects[0].elements)),
+         materials_in=np.stack([e.material.as_floats() for e in sc.objects[0].elements]),
+         hit_ro=ro, hit_rd=rd, hit_tri=tri, hit_tuv=tuv,
+         di_p=p, di_n=nn, di_diffuse=dif, di_tape=tape, di_out=out, **scene_arrays_dict(arr))
+
+
+def tier_t(ref: Ref, tmp: str):
+    """Draw-tape paths (SURVEY.md §8c4 tier T)."""
+    for kind, nrays, depth in [("cornell", 192, 4), ("glossy", 256, 5), ("glass", 256, 6), ("textured", 256, 4)]:
+        rng = np.random.default_rng(17 + 101 * len(kind) + depth)
+        sc = micro_scene(kind, tmp)
+        sc.trace_depth = depth
+        ref.load_scene(sc)
+        arr = arrays_from_ref(ref, sc)
+        ro = np.tile(np.array([0.0, 0.0, -3.5], np.float32), (nrays, 1))
+        # irrational offsets keep rays off shared edges / diagonals (ties depend on the random tree)
+        rd = np.stack([rng.uniform(-.46, .46, nrays) + 0.00137, rng.uniform(-.46, .46, nrays) + 0.00071,
+                       np.ones(nrays)], 1)
+        rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+        tapes, counts, rad = [], [], np.zeros((nrays, 3), np.float32)
+        for i in range(nrays):
+            ref.lib.ref_seed(31000 + i)
+            t = ref.peek_tape(4096)
+            ref.lib.ref_mark()
+            rad[i] = ref.trace(ro[i], rd[i])
+            nd = ref.lib.ref_draws_since_mark(4096)
+            assert nd >= 0
+            counts.append(nd)
+            tapes.append(t[: nd + 4])
+        offs = np.concatenate([[0], np.cumsum([len(t) for t in tapes])]).astype(np.int64)
+        save(f"tier_t_{kind}.npz", depth=np.int32(depth), ro=ro, rd=rd, radiance=rad,
+             tape=np.concatenate(tapes), tape_off=offs, ndraws=np.array(counts, np.int32),
+             **scene_arrays_dict(arr))
+
+
+def tier_s(ref: Ref, tmp: str):
+    """Converged mean images through RenderFrame as shipped (OpenMP, shared engine)."""
+    for kind, res, depth, spp in [("cornell", 48, 4, 4096), ("opacity", 40, 5, 3072), ("glass", 40, 6, 3072)]:
+        sc = micro_scene(kind, tmp)
+        sc.trace_depth = depth; sc.width = sc.height = res
+        ref.load_scene(sc)
+        arr = arrays_from_ref(ref, sc)
+        cam, proj = camera_dict(ref)
+        ref.lib.ref_seed(424242)
+        half = spp // 2
+        ref.render(half)
+        t1 = ref.total(res, res) / half
+        ref.render(spp - half)
+        tot = ref.total(res, res)
+        t2 = (tot - t1 * half) / (spp - half)
+        save(f"tier_s_{kind}.npz", width=np.int32(res), height=np.int32(res), depth=np.int32(depth), spp=np.int32(spp),
+             cam=cam, proj=proj, focal_dist=np.float32(sc.focal_dist), aperture=np.float32(np.float32(S.PTS_FOCAL) / np.float32(sc.camera_f)),
+             mean=(tot / spp).astype(np.float32), mean_half1=t1.astype(np.float32), mean_half2=t2.astype(np.float32),
+             rgb8=ref.rgb8(res, res), **scene_arrays_dict(arr))
+
+
+def main():
+    ref = Ref()
+    with tempfile.TemporaryDirectory() as tmp:
+        tier_k(ref, tmp)
+        tier_k_scene(ref, tmp)
+        tier_t(ref, tmp)
+        tier_s(ref, tmp)
+
+
+if __name__ == "__main__":
+    main()

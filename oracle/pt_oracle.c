@@ -571,7 +571,7 @@ static int shade(const orc_scene* s, v3 ro, v3 rd, const hit_t* h, int D, int* d
     return 1;
 }
 
-/* PathTracer::Trace pathtracer.cpp:545-732, ITERATIVE form: L += T*(emission + direct); T *= weight.
+/* PathTracer::Trace pathtracer.cpp:545-732, ITERATIVE form: L += T*emission; L += T*direct; T *= weight.
  * This is the estimator the HIP kernel implements and the one orc_render uses.  Draw order per
  * bounce: [RR] branch, direction (w, theta), then the three DirectIllumimation draws. */
 static v3 trace(const orc_scene* s, v3 ro, v3 rd, int D, rng_t* rng)
@@ -584,13 +584,12 @@ static v3 trace(const orc_scene* s, v3 ro, v3 rd, int D, rng_t* rng)
         hit_t h; bounce_t b;
         if (!closest_hit(s, ro, rd, rng, ray++, &h)) break;                  /* :550 */
         if (!shade(s, ro, rd, &h, D, &depth, &iter, &inside, rng, &b)) break;
-        v3 e = b.e;
+        L = add(L, mulv(T, b.e));                                            /* emiss * I */
         if (b.diffuse_bounce)
         {
             v3 di = direct_illumination(s, b.p, b.n, b.diffuse, rng, &ray);   /* :638 / :724 */
-            e = add(e, di);
+            L = add(L, mulv(T, di));
         }
-        L = add(L, mulv(T, e));
         T = mulv(T, b.weight);
         ro = b.p; rd = b.dir;
     }

@@ -1,0 +1,636 @@
+// Host side of the ptk C-ABI (include/ptk.h): context, scene staging into the device record layouts
+// of ptk_device.h, BVH build, kernel launches, hand-off copies, RCCL exchange step.
+//
+// Reference behaviour restated here (PathTracing/src/pathtracer.cpp): BuildBVH + light list :260-274,
+// setters :297-360, frame set-up arithmetic of RenderFrame :755-766, reset :745-751.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "ptk_device.h"
+
+using namespace ptk;
+
+struct ptk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string error;
+    std::mutex err_mu;
+
+    // scene (device)
+    float4 *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+    int4* d_texinfo = nullptr;
+    uint32_t* d_texels = nullptr;
+    int num_nodes = 0, num_tris = 0, num_lights = 0, bvh_depth = 0, num_leaf_tris = 0;
+    bool have_scene = false;
+
+    // camera (host copies, already normalised / clamped like the reference setters)
+    float cam_pos[3] = { 0, 0, 0 }, cam_dir[3] = { 0, 0, 1 }, cam_up[3] = { 0, 1, 0 };
+    float focal = 0.1f, fovy = 90.0f, focal_dist = 5.0f, aperture = 0.0f;   // pathtracer.cpp:17-22
+    float cam_right[3] = { 1, 0, 0 };
+    bool primary_dirty = true;
+
+    // frame
+    int width = 0, height = 0, max_depth = 3;                                 // pathtracer.cpp:15
+    float4* d_primary = nullptr;
+    float* d_accum = nullptr;        // owned accumulator
+    float* d_accum_bound = nullptr;  // caller-owned accumulator (ptk_bind_accum) or null
+    uint8_t* d_rgb8 = nullptr;
+    int rank = 0, world = 1;
+
+    std::atomic<int> samples{ 0 };
+    std::atomic<uint32_t> exit_req{ 0 };
+    uint32_t* d_exit = nullptr;
+    unsigned long long* d_stats = nullptr;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int last_launches = 0;
+    bool timed = false;
+};
+
+namespace {
+
+int fail(ptk_ctx* c, int code, const std::string& msg)
+{
+    if (c) { std::lock_guard<std::mutex> g(c->err_mu); c->error = msg; }
+    return code;
+}
+#define HIPCHK(c, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(c, PTK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+template <class T>
+void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+float* accum_ptr(ptk_ctx* c) { return c->d_accum_bound ? c->d_accum_bound : c->d_accum; }
+
+inline float as_float(int32_t i) { float f; std::memcpy(&f, &i, 4); return f; }
+
+void normalize3(const float* in, float* out)
+{
+    // glm::normalize = x * (1 / sqrt(dot(x, x)))   (pathtracer.cpp:336-337)
+    float sqr = in[0] * in[0] + in[1] * in[1] + in[2] * in[2];
+    float inv = 1.0f / std::sqrt(sqr);
+    out[0] = in[0] * inv; out[1] = in[1] * inv; out[2] = in[2] * inv;
+}
+
+// image-plane set-up of RenderFrame, pathtracer.cpp:755-766 (host, once per camera/resolution change)
+void frame_setup(ptk_ctx* c, PrimaryParams& pp)
+{
+    const float* pos = c->cam_pos; const float* dir = c->cam_dir; const float* up = c->cam_up;
+    float center[3] = { pos[0] + dir[0] * c->focal, pos[1] + dir[1] * c->focal, pos[2] + dir[2] * c->focal };
+    float img_h = (float)((double)(2.0f * c->focal) * std::tan((double)(c->fovy / 2.0f) * 3.14159265358979323846 / (double)180.0f));
+    float aspect = (float)c->width / (float)c->height;
+    float img_w = img_h * aspect;
+    pp.delta_x = img_w / (float)c->width;
+    pp.delta_y = img_h / (float)c->height;
+    // camRight = normalize(cross(up, dir))
+    float cr[3] = { up[1] * dir[2] - dir[1] * up[2], up[2] * dir[0] - dir[2] * up[0], up[0] * dir[1] - dir[0] * up[1] };
+    normalize3(cr, c->cam_right);
+    float hw = img_w * 0.5f, hh = img_h * 0.5f;
+    for (int a = 0; a < 3; a++)
+    {
+        float tl = center[a] - c->cam_right[a] * hw;
+        tl = tl + up[a] * hh;
+        pp.top_left[a] = tl;
+        pp.cam_pos[a] = pos[a]; pp.cam_right[a] = c->cam_right[a]; pp.cam_up[a] = up[a];
+    }
+    pp.primary = c->d_primary; pp.width = c->width; pp.height = c->height;
+}
+
+int ensure_primary(ptk_ctx* c)
+{
+    if (!c->primary_dirty) return PTK_OK;
+    if (!c->d_primary) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    PrimaryParams pp;
+    frame_setup(c, pp);
+    launch_primary(pp, c->stream);
+    HIPCHK(c, hipGetLastError());
+    c->primary_dirty = false;
+    return PTK_OK;
+}
+
+void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint64_t seed)
+{
+    std::memset(&p, 0, sizeof(p));
+    p.nodes = c->d_nodes; p.tris = c->d_tris; p.shade = c->d_shade; p.mats = c->d_mats; p.lights = c->d_lights;
+    p.texinfo = c->d_texinfo; p.texels = c->d_texels; p.primary = c->d_primary;
+    p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.stats = c->d_stats;
+    p.num_nodes = c->num_nodes; p.num_lights = c->num_lights;
+    p.width = c->width; p.height = c->height; p.max_depth = c->max_depth;
+    p.tiles_x = (c->width + PTK_TILE - 1) / PTK_TILE;
+    p.num_tiles = p.tiles_x * ((c->height + PTK_TILE - 1) / PTK_TILE);
+    p.rank = c->rank; p.world = c->world;
+    p.first_sample = first; p.spp = spp;
+    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+    for (int a = 0; a < 3; a++) { p.cam_pos[a] = c->cam_pos[a]; p.cam_right[a] = c->cam_right[a]; p.cam_up[a] = c->cam_up[a]; }
+    p.focal_dist = c->focal_dist; p.aperture = c->aperture;
+    p.resolve_samples = (float)(first + spp);
+}
+
+int my_blocks(const RenderParams& p)
+{
+    // tiles t with t % world == rank
+    if (p.num_tiles <= p.rank) return 0;
+    return (p.num_tiles - p.rank + p.world - 1) / p.world;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptk_create(ptk_ctx** out, int device_ordinal)
+{
+    if (!out) return PTK_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return PTK_ERR_HIP;
+    if (device_ordinal < 0 || device_ordinal >= ndev) return PTK_ERR_BAD_ARG;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return PTK_ERR_HIP;
+    ptk_ctx* c = new (std::nothrow) ptk_ctx();
+    if (!c) return PTK_ERR_HIP;
+    c->device = device_ordinal;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PTK_ERR_HIP; }
+    c->own_stream = true;
+    if (hipMalloc(&c->d_exit, sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_exit, 0, sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+    {
+        ptk_destroy(c);
+        return PTK_ERR_HIP;
+    }
+    *out = c;
+    return PTK_OK;
+}
+
+void ptk_destroy(ptk_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_mats); dfree(c->d_lights);
+    dfree(c->d_texinfo); dfree(c->d_texels); dfree(c->d_primary); dfree(c->d_accum); dfree(c->d_rgb8);
+    dfree(c->d_exit); dfree(c->d_stats);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* ptk_last_error(ptk_ctx* c)
+{
+    if (!c) return "null context";
+    std::lock_guard<std::mutex> g(c->err_mu);
+    return c->error.c_str();
+}
+
+int ptk_set_stream(ptk_ctx* c, void* s)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    c->stream = (hipStream_t)s;
+    c->own_stream = false;
+    return PTK_OK;
+}
+
+int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
+{
+    if (!c || !s) return PTK_ERR_BAD_ARG;
+    const int32_t n = s->num_triangles;
+    if (n < 0 || s->num_materials < 0 || s->num_textures < 0 || s->num_lights < 0)
+        return fail(c, PTK_ERR_BAD_ARG, "negative count in scene description");
+    if (n > 0 && (!s->verts || !s->normals || !s->uvs || !s->tbn || !s->smoothing || !s->material || !s->materials))
+        return fail(c, PTK_ERR_BAD_ARG, "null triangle/material array");
+    if (s->num_lights > 0 && !s->lights) return fail(c, PTK_ERR_BAD_ARG, "null light array");
+    if (s->num_textures > 0 && (!s->textures || !s->texels)) return fail(c, PTK_ERR_BAD_ARG, "null texture array");
+    for (int32_t i = 0; i < n; i++)
+        if (s->material[i] < 0 || s->material[i] >= s->num_materials)
+            return fail(c, PTK_ERR_BAD_ARG, "triangle material index out of range");
+    for (int32_t i = 0; i < s->num_lights; i++)
+        if (s->lights[i] < 0 || s->lights[i] >= n) return fail(c, PTK_ERR_BAD_ARG, "light triangle index out of range");
+    for (int32_t i = 0; i < s->num_textures; i++)
+    {
+        const ptk_texture& t = s->textures[i];
+        if (t.width < 0 || t.height < 0 || t.offset < 0 || (t.offset & 3) ||
+            t.offset + (int64_t)t.width * t.height * 4 > s->texel_bytes)
+            return fail(c, PTK_ERR_BAD_ARG, "texture outside the texel atlas");
+    }
+    for (int32_t i = 0; i < s->num_materials; i++)
+        for (int k = 0; k < 6; k++)
+            if (s->materials[i].tex[k] >= s->num_textures) return fail(c, PTK_ERR_BAD_ARG, "material texture index out of range");
+
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+
+    BuiltBvh bvh;
+    if (!build_bvh(s->verts, n, PTK_MAX_BVH_DEPTH, 4, bvh))
+        return fail(c, PTK_ERR_LIMIT, "BVH exceeds the kernel's depth / index limits");
+    if (bvh.depth > PTK_MAX_BVH_DEPTH) return fail(c, PTK_ERR_LIMIT, "BVH deeper than the LDS traversal stack");
+
+    // a texture with zero extent behaves like a missing image: tex2D returns 0 (image.cpp:65-66);
+    // staged as a 1x1 black texel so the kernel needs no special case
+    std::vector<int32_t> texmap(s->num_textures, -1);
+    std::vector<int4> texinfo;
+    std::vector<uint32_t> texels;
+    texels.push_back(0u);                                   // texel 0: shared black texel
+    for (int32_t i = 0; i < s->num_textures; i++)
+    {
+        const ptk_texture& t = s->textures[i];
+        int4 ti;
+        if (t.width == 0 || t.height == 0) { ti = make_int4(1, 1, 0, 0); }
+        else
+        {
+            ti = make_int4(t.width, t.height, (int)texels.size(), 0);
+            size_t cnt = (size_t)t.width * t.height;
+            size_t base = texels.size();
+            texels.resize(base + cnt);
+            std::memcpy(texels.data() + base, s->texels + t.offset, cnt * 4);
+        }
+        texmap[i] = (int32_t)texinfo.size();
+        texinfo.push_back(ti);
+    }
+    if (texels.size() >= (1ull << 31)) return fail(c, PTK_ERR_LIMIT, "texel atlas too large");
+
+    std::vector<float> mats((size_t)s->num_materials * MAT_F4 * 4, 0.0f);
+    for (int32_t i = 0; i < s->num_materials; i++)
+    {
+        const ptk_material& m = s->materials[i];
+        float* q = mats.data() + (size_t)i * MAT_F4 * 4;
+        q[0] = m.diffuse[0]; q[1] = m.diffuse[1]; q[2] = m.diffuse[2]; q[3] = as_float(m.type != 0 ? 1 : 0);
+        q[4] = m.specular[0]; q[5] = m.specular[1]; q[6] = m.specular[2]; q[7] = m.emissive_intensity;
+        q[8] = m.emissive[0]; q[9] = m.emissive[1]; q[10] = m.emissive[2]; q[11] = m.roughness;
+        // Russian-roulette probability, pathtracer.cpp:589: glm::min(0.95f, glm::max(glm::max(d.x, d.y), d.z))
+        float mx = m.diffuse[0] < m.diffuse[1] ? m.diffuse[1] : m.diffuse[0];
+        mx = mx < m.diffuse[2] ? m.diffuse[2] : mx;
+        float prob = 0.95f < mx ? 0.95f : mx;
+        q[12] = m.reflectiveness; q[13] = m.translucency; q[14] = m.ior; q[15] = prob;
+        int any = 0;
+        for (int k = 0; k < 6; k++)
+        {
+            int32_t t = m.tex[k] >= 0 ? texmap[m.tex[k]] : -1;
+            q[16 + k] = as_float(t);
+            if (t >= 0) any = 1;
+        }
+        q[22] = as_float(any); q[23] = 0.0f;
+    }
+
+    std::vector<float> tris((size_t)n * TRI_F4 * 4, 0.0f);
+    c->num_leaf_tris = n;
+    for (int32_t k = 0; k < n; k++)
+    {
+        int32_t i = bvh.order[k];
+        const float* v = s->verts + (size_t)i * 9;
+        float* q = tris.data() + (size_t)k * TRI_F4 * 4;
+        q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+        q[3] = v[3] - v[0]; q[4] = v[4] - v[1]; q[5] = v[5] - v[2];      // edge1 = v2 - v1 (pathtracer.cpp:382)
+        q[6] = v[6] - v[0]; q[7] = v[7] - v[1]; q[8] = v[8] - v[2];      // edge2 = v3 - v1 (pathtracer.cpp:383)
+        q[9] = as_float(i);
+        int32_t ot = s->materials[s->material[i]].tex[5];
+        q[10] = as_float(ot >= 0 ? texmap[ot] : -1);
+        q[11] = 0.0f;
+    }
+    std::vector<float> shade((size_t)n * SHADE_F4 * 4, 0.0f);
+    for (int32_t i = 0; i < n; i++)
+    {
+        const float* nn = s->normals + (size_t)i * 9;
+        const float* uv = s->uvs + (size_t)i * 6;
+        const float* tb = s->tbn + (size_t)i * 9;
+        float* q = shade.data() + (size_t)i * SHADE_F4 * 4;
+        q[0] = tb[0]; q[1] = tb[1]; q[2] = tb[2];
+        q[3] = as_float((int32_t)((uint32_t)s->material[i] | (s->smoothing[i] ? 0x80000000u : 0u)));
+        q[4] = uv[0]; q[5] = uv[1]; q[6] = uv[2]; q[7] = uv[3];
+        q[8] = uv[4]; q[9] = uv[5]; q[10] = nn[0]; q[11] = nn[1];
+        q[12] = nn[2]; q[13] = nn[3]; q[14] = nn[4]; q[15] = nn[5];
+        q[16] = nn[6]; q[17] = nn[7]; q[18] = nn[8]; q[19] = tb[3];
+        q[20] = tb[4]; q[21] = tb[5]; q[22] = tb[6]; q[23] = tb[7];
+        q[24] = tb[8];
+    }
+    std::vector<float> lights((size_t)s->num_lights * LIGHT_F4 * 4, 0.0f);
+    for (int32_t k = 0; k < s->num_lights; k++)
+    {
+        int32_t i = s->lights[k];
+        const float* v = s->verts + (size_t)i * 9;
+        const ptk_material& m = s->materials[s->material[i]];
+        float* q = lights.data() + (size_t)k * LIGHT_F4 * 4;
+        q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = as_float(i);
+        q[4] = v[3]; q[5] = v[4]; q[6] = v[5]; q[7] = m.emissive[0] * m.emissive_intensity;    // pathtracer.cpp:528
+        q[8] = v[6]; q[9] = v[7]; q[10] = v[8]; q[11] = m.emissive[1] * m.emissive_intensity;
+        q[12] = m.emissive[2] * m.emissive_intensity;
+    }
+
+    dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_mats); dfree(c->d_lights);
+    dfree(c->d_texinfo); dfree(c->d_texels);
+    c->have_scene = false;
+    auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        size_t alloc = bytes ? bytes : 16;
+        hipError_t e = hipMalloc(dst, alloc);
+        if (e != hipSuccess) return e;
+        if (bytes) return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return hipSuccess;
+    };
+    HIPCHK(c, up((void**)&c->d_nodes, bvh.nodes.data(), bvh.nodes.size() * 4));
+    HIPCHK(c, up((void**)&c->d_tris, tris.data(), tris.size() * 4));
+    HIPCHK(c, up((void**)&c->d_shade, shade.data(), shade.size() * 4));
+    HIPCHK(c, up((void**)&c->d_mats, mats.data(), mats.size() * 4));
+    HIPCHK(c, up((void**)&c->d_lights, lights.data(), lights.size() * 4));
+    HIPCHK(c, up((void**)&c->d_texinfo, texinfo.data(), texinfo.size() * sizeof(int4)));
+    HIPCHK(c, up((void**)&c->d_texels, texels.data(), texels.size() * 4));
+    c->num_nodes = bvh.num_nodes; c->num_tris = n; c->num_lights = s->num_lights; c->bvh_depth = bvh.depth;
+    c->have_scene = true;
+    return PTK_OK;
+}
+
+int ptk_set_camera(ptk_ctx* c, const float pos[3], const float dir[3], const float up[3],
+                   float focal, float fovy_deg, float focal_dist, float aperture)
+{
+    if (!c || !pos || !dir || !up) return PTK_ERR_BAD_ARG;
+    for (int a = 0; a < 3; a++) c->cam_pos[a] = pos[a];
+    normalize3(dir, c->cam_dir);                           // pathtracer.cpp:336
+    normalize3(up, c->cam_up);                             // pathtracer.cpp:337
+    c->focal = focal;                                      // SetProjection, pathtracer.cpp:340-350
+    if (c->focal <= 0.0f) c->focal = 0.1f;
+    c->fovy = fovy_deg;
+    if (c->fovy <= 0.0f) c->fovy = 0.1f;
+    else if (c->fovy >= 180.0f) c->fovy = 179.5;
+    c->focal_dist = focal_dist;
+    c->aperture = aperture;
+    c->primary_dirty = true;
+    return PTK_OK;
+}
+
+int ptk_set_frame(ptk_ctx* c, int width, int height, int max_depth)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (1ll << 28)) return fail(c, PTK_ERR_BAD_ARG, "bad resolution");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->max_depth = max_depth;
+    if (width != c->width || height != c->height || !c->d_accum)
+    {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dfree(c->d_primary); dfree(c->d_accum); dfree(c->d_rgb8);
+        size_t px = (size_t)width * height;
+        HIPCHK(c, hipMalloc(&c->d_primary, px * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_accum, px * 3 * sizeof(float)));
+        HIPCHK(c, hipMalloc(&c->d_rgb8, px * 3));
+        c->width = width; c->height = height;
+        c->d_accum_bound = nullptr;
+        HIPCHK(c, hipMemsetAsync(c->d_accum, 0, px * 3 * sizeof(float), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_rgb8, 0, px * 3, c->stream));
+        c->samples = 0;
+        c->primary_dirty = true;
+    }
+    return PTK_OK;
+}
+
+int ptk_set_tile(ptk_ctx* c, int rank, int world)
+{
+    if (!c || world < 1 || rank < 0 || rank >= world) return PTK_ERR_BAD_ARG;
+    c->rank = rank; c->world = world;
+    return PTK_OK;
+}
+
+int ptk_reset(ptk_ctx* c)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    if (!accum_ptr(c)) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t px = (size_t)c->width * c->height;
+    HIPCHK(c, hipMemsetAsync(accum_ptr(c), 0, px * 3 * sizeof(float), c->stream));     // pathtracer.cpp:745-751
+    HIPCHK(c, hipMemsetAsync(c->d_rgb8, 0, px * 3, c->stream));
+    c->samples = 0;
+    c->exit_req = 0;
+    HIPCHK(c, hipMemsetAsync(c->d_exit, 0, sizeof(uint32_t), c->stream));
+    return PTK_OK;
+}
+
+int ptk_render(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uint64_t seed)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    if (!c->have_scene) return fail(c, PTK_ERR_BAD_ARG, "ptk_upload_scene has not been called");
+    if (!accum_ptr(c) || !c->d_primary) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    if (c->bvh_depth > PTK_MAX_BVH_DEPTH) return fail(c, PTK_ERR_LIMIT, "BVH deeper than the LDS traversal stack");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->last_launches = 0;
+    c->timed = false;
+    if (spp_count == 0) return PTK_OK;
+    if (c->exit_req.load())
+    {
+        // Exit() before the frame started: the frame's work is skipped but the count still advances
+        // (mSamples++ precedes the loop and is not rolled back, pathtracer.cpp:753, :779-780)
+        c->samples = (int)(first_sample + spp_count);
+        return PTK_OK;
+    }
+    int rc = ensure_primary(c);
+    if (rc != PTK_OK) return rc;
+    RenderParams p;
+    fill_params(c, p, first_sample, spp_count, seed);
+    int blocks = my_blocks(p);
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    launch_render(p, blocks, c->stream, false);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->last_launches = blocks > 0 ? 1 : 0;
+    c->timed = true;
+    c->samples = (int)(first_sample + spp_count);
+    return PTK_OK;
+}
+
+int ptk_collect_stats(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uint64_t seed, ptk_stats* out)
+{
+    if (!c || !out) return PTK_ERR_BAD_ARG;
+    if (!c->have_scene || !c->d_primary) return fail(c, PTK_ERR_BAD_ARG, "scene / frame not set");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_primary(c);
+    if (rc != PTK_OK) return rc;
+    // untimed counters-enabled variant; renders into a scratch accumulator so the image is untouched
+    size_t px = (size_t)c->width * c->height;
+    float* scratch = nullptr; uint8_t* scratch8 = nullptr;
+    HIPCHK(c, hipMalloc(&scratch, px * 3 * sizeof(float)));
+    if (hipMalloc(&scratch8, px * 3) != hipSuccess) { (void)hipFree(scratch); return fail(c, PTK_ERR_HIP, "hipMalloc"); }
+    (void)hipMemsetAsync(scratch, 0, px * 3 * sizeof(float), c->stream);
+    (void)hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), c->stream);
+    RenderParams p;
+    fill_params(c, p, first_sample, spp_count, seed);
+    p.accum = scratch; p.rgb8 = scratch8; p.exit_flag = nullptr;
+    launch_render(p, my_blocks(p), c->stream, true);
+    unsigned long long h[8] = { 0 };
+    hipError_t e = hipMemcpyAsync(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(scratch); (void)hipFree(scratch8);
+    if (e != hipSuccess) return fail(c, PTK_ERR_HIP, hipGetErrorString(e));
+    out->samples = h[0]; out->rays = h[1]; out->shadow_rays = h[2]; out->node_visits = h[3];
+    out->tri_tests = h[4]; out->hits_shaded = h[5]; out->tex_fetches = h[6];
+    return PTK_OK;
+}
+
+int ptk_resolve_rgb8(ptk_ctx* c, uint8_t* host_out)
+{
+    if (!c || !host_out) return PTK_ERR_BAD_ARG;
+    if (!c->d_rgb8) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(host_out, c->d_rgb8, (size_t)c->width * c->height * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PTK_OK;
+}
+
+int ptk_read_accum(ptk_ctx* c, float* host_out)
+{
+    if (!c || !host_out) return PTK_ERR_BAD_ARG;
+    if (!accum_ptr(c)) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(host_out, accum_ptr(c), (size_t)c->width * c->height * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PTK_OK;
+}
+
+int ptk_write_accum(ptk_ctx* c, const float* host_in, int samples)
+{
+    if (!c || !host_in || samples < 0) return PTK_ERR_BAD_ARG;
+    if (!accum_ptr(c)) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(accum_ptr(c), host_in, (size_t)c->width * c->height * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->samples = samples;
+    return PTK_OK;
+}
+
+int ptk_samples(ptk_ctx* c) { return c ? c->samples.load() : 0; }
+
+int ptk_request_exit(ptk_ctx* c)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    c->exit_req = 1;
+    // blocks that have not started yet read the flag and return (kernel prologue); written with a
+    // blocking copy outside the render stream so it lands while a render is in flight
+    uint32_t one = 1;
+    (void)hipSetDevice(c->device);
+    (void)hipMemcpy(c->d_exit, &one, sizeof(one), hipMemcpyHostToDevice);
+    return PTK_OK;
+}
+
+int ptk_synchronize(ptk_ctx* c)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PTK_OK;
+}
+
+int ptk_accum_device_ptr(ptk_ctx* c, void** dev_ptr, size_t* bytes)
+{
+    if (!c || !dev_ptr) return PTK_ERR_BAD_ARG;
+    *dev_ptr = accum_ptr(c);
+    if (bytes) *bytes = (size_t)c->width * c->height * 3 * sizeof(float);
+    return *dev_ptr ? PTK_OK : fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+}
+
+int ptk_rgb8_device_ptr(ptk_ctx* c, void** dev_ptr, size_t* bytes)
+{
+    if (!c || !dev_ptr) return PTK_ERR_BAD_ARG;
+    *dev_ptr = c->d_rgb8;
+    if (bytes) *bytes = (size_t)c->width * c->height * 3;
+    return *dev_ptr ? PTK_OK : fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+}
+
+int ptk_bind_accum(ptk_ctx* c, void* dev_ptr)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    if (!c->d_accum) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    c->d_accum_bound = (float*)dev_ptr;
+    return PTK_OK;
+}
+
+int ptk_gather_accum(ptk_ctx* c, void* rccl_comm, int root)
+{
+    if (!c || !rccl_comm) return PTK_ERR_BAD_ARG;
+    if (!accum_ptr(c)) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t count = (size_t)c->width * c->height * 3;
+    // pixels of tiles a rank does not own stay exactly 0.0f, so the sum over ranks reproduces every
+    // owned value bit for bit: a gather expressed as one reduce over xGMI
+    ncclResult_t r = ncclReduce(accum_ptr(c), accum_ptr(c), count, ncclFloat, ncclSum, root, (ncclComm_t)rccl_comm, c->stream);
+    if (r != ncclSuccess) return fail(c, PTK_ERR_RCCL, std::string("ncclReduce: ") + ncclGetErrorString(r));
+    return PTK_OK;
+}
+
+int ptk_last_render_ms(ptk_ctx* c, float* ms, int* launches)
+{
+    if (!c || !ms) return PTK_ERR_BAD_ARG;
+    *ms = 0.0f;
+    if (launches) *launches = c->last_launches;
+    if (!c->timed) return PTK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PTK_OK;
+}
+
+int ptk_bvh_info(ptk_ctx* c, int32_t* num_nodes, int32_t* depth, int32_t* num_leaf_tris)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    if (num_nodes) *num_nodes = c->num_nodes;
+    if (depth) *depth = c->bvh_depth;
+    if (num_leaf_tris) *num_leaf_tris = c->num_leaf_tris;
+    return PTK_OK;
+}
+
+int ptk_probe_hits(ptk_ctx* c, int n, const float* ro, const float* rd, int32_t* tri, float* tuv)
+{
+    if (!c || n < 0 || (n > 0 && (!ro || !rd || !tri || !tuv))) return PTK_ERR_BAD_ARG;
+    if (!c->have_scene) return fail(c, PTK_ERR_BAD_ARG, "ptk_upload_scene has not been called");
+    if (n == 0) return PTK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d_ro = nullptr, *d_rd = nullptr, *d_tuv = nullptr; int32_t* d_tri = nullptr;
+    size_t b3 = (size_t)n * 3 * sizeof(float);
+    hipError_t e = hipMalloc(&d_ro, b3);
+    if (e == hipSuccess) e = hipMalloc(&d_rd, b3);
+    if (e == hipSuccess) e = hipMalloc(&d_tuv, b3);
+    if (e == hipSuccess) e = hipMalloc(&d_tri, (size_t)n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ro, ro, b3, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rd, rd, b3, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+    {
+        ProbeParams p;
+        p.nodes = c->d_nodes; p.tris = c->d_tris; p.shade = c->d_shade; p.mats = c->d_mats;
+        p.texinfo = c->d_texinfo; p.texels = c->d_texels; p.ro = d_ro; p.rd = d_rd; p.tri = d_tri; p.tuv = d_tuv;
+        p.n = n; p.num_nodes = c->num_nodes;
+        launch_probe(p, c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(tri, d_tri, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tuv, d_tuv, b3, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_ro); (void)hipFree(d_rd); (void)hipFree(d_tuv); (void)hipFree(d_tri);
+    if (e != hipSuccess) return fail(c, PTK_ERR_HIP, hipGetErrorString(e));
+    return PTK_OK;
+}
+
+int ptk_probe_primary_dirs(ptk_ctx* c, float* host_out)
+{
+    if (!c || !host_out) return PTK_ERR_BAD_ARG;
+    if (!c->d_primary) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_primary(c);
+    if (rc != PTK_OK) return rc;
+    size_t px = (size_t)c->width * c->height;
+    std::vector<float4> tmp(px);
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_primary, px * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < px; i++) { host_out[i * 3] = tmp[i].x; host_out[i * 3 + 1] = tmp[i].y; host_out[i * 3 + 2] = tmp[i].z; }
+    return PTK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Shared between the host API (ptk_api.hip) and the kernels (ptk_kernels.hip): device record layouts
+// and the by-value kernel parameter block.  All records are float4-aligned so one lane fetches a
+// record with 16-byte loads (global_load_dwordx4).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ptk.h"
+
+namespace ptk {
+
+// BVH2 node, 64 B: both child boxes live in the parent so one record feeds two slab tests.
+//   q0 = (lmin.x, lmin.y, lmin.z, lmax.x)   q1 = (lmax.y, lmax.z, rmin.x, rmin.y)
+//   q2 = (rmin.z, rmax.x, rmax.y, rmax.z)   q3 = (bits left, bits right, 0, 0)
+// child >= 0: interior node index; child < 0: leaf, ~child = (first_record << 3) | (count - 1)
+constexpr int NODE_F4 = 4;
+constexpr int LEAF_MAX = 8;
+constexpr int32_t NODE_EXIT = INT32_MIN;
+
+// Triangle intersection record, 48 B, stored in BVH leaf order:
+//   t0 = (v0.xyz, e1.x)  t1 = (e1.yz, e2.xy)  t2 = (e2.z, bits tri_index, bits opacity_tex, 0)
+constexpr int TRI_F4 = 3;
+
+// Shading record, 112 B, indexed by the scene's triangle index (fetched only for the accepted hit):
+//   s0 = (normal.xyz, bits (material | smoothing << 31))
+//   s1 = (uv1.xy, uv2.xy)  s2 = (uv3.xy, n1.xy)  s3 = (n1.z, n2.xyz)  s4 = (n3.xyz, tangent.x)
+//   s5 = (tangent.yz, bitangent.xy)  s6 = (bitangent.z, 0, 0, 0)
+constexpr int SHADE_F4 = 7;
+
+// Material record, 96 B:
+//   m0 = (diffuse.rgb, bits type)  m1 = (specular.rgb, emissiveIntensity)  m2 = (emissive.rgb, roughness)
+//   m3 = (reflectiveness, translucency, ior, rr_prob)  m4 = bits tex[0..3]  m5 = bits (tex[4], tex[5], any_tex, 0)
+constexpr int MAT_F4 = 6;
+
+// Light record, 64 B:  l0 = (v1.xyz, bits tri)  l1 = (v2.xyz, c.r)  l2 = (v3.xyz, c.g)  l3 = (c.b, 0, 0, 0)
+// with c = emissive * emissiveIntensity of the light's material (pathtracer.cpp:528)
+constexpr int LIGHT_F4 = 4;
+
+struct RenderParams {
+    const float4* nodes;
+    const float4* tris;
+    const float4* shade;
+    const float4* mats;
+    const float4* lights;
+    const int4* texinfo;        // (width, height, first texel index, 0)
+    const uint32_t* texels;     // RGBA8 atlas as packed words (r = low byte)
+    const float4* primary;      // [H][W] unit primary directions before DOF (top-down rows)
+    float* accum;               // [H][W][3] float RGB, rows bottom-up (mTotalImg)
+    uint8_t* rgb8;              // [H][W][3] RGB8, rows bottom-up (mOutImg)
+    const uint32_t* exit_flag;
+    unsigned long long* stats;  // 7 counters (STATS variant only)
+    int num_nodes, num_lights;
+    int width, height, max_depth;
+    int tiles_x, num_tiles;
+    int rank, world;
+    uint32_t first_sample, spp;
+    uint32_t seed_lo, seed_hi;
+    float cam_pos[3], cam_right[3], cam_up[3];
+    float focal_dist, aperture;
+    float resolve_samples;      // (float)(first_sample + spp) = (float)mSamples
+};
+
+struct PrimaryParams {
+    float4* primary;
+    int width, height;
+    float cam_pos[3], cam_right[3], cam_up[3], top_left[3];
+    float delta_x, delta_y;
+};
+
+struct ProbeParams {
+    const float4* nodes;
+    const float4* tris;
+    const float4* shade;
+    const float4* mats;
+    const int4* texinfo;
+    const uint32_t* texels;
+    const float* ro;
+    const float* rd;
+    int32_t* tri;
+    float* tuv;
+    int n, num_nodes;
+};
+
+void launch_render(const RenderParams& p, int blocks, hipStream_t stream, bool stats);
+void launch_primary(const PrimaryParams& p, hipStream_t stream);
+void launch_probe(const ProbeParams& p, hipStream_t stream);
+
+}  // namespace ptk

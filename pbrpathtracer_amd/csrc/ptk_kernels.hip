@@ -1,0 +1,623 @@
+// HIP kernels for gfx950 (CDNA4, wave64): the per-pixel render loop of the reference
+//   PathTracer::RenderFrame -> Trace -> Hit -> {IntersectTriangle, Image::tex2D, DirectIllumimation}
+//   (reference PathTracing/src/pathtracer.cpp:367-822, mesh.cpp:48-59, image.cpp:63-86)
+// as ONE megakernel: one path per lane, one 16x16 pixel tile per 256-thread block (four 8x8 waves).
+//
+// Design (not a translation of the reference's recursion):
+//   * Trace is iterative: L += T*e; L += T*direct; T *= weight, with the reference's two counters
+//     (depth arms Russian roulette, iter is the hard stop) and its quirks kept.
+//   * A lane is a small state machine {bounce ray, shadow ray}; bounce and shadow rays of different
+//     lanes share one traversal loop, and a lane whose path ends immediately starts the next sample
+//     of its pixel ("path regeneration"), so the wave stays full until the spp batch is done.  The
+//     float3 accumulator stays in registers for the whole batch: one read-modify-write per launch.
+//   * Closest hit: BVH2 with both child boxes in the 64-byte parent record, ordered descent with
+//     t-max culling, per-lane stack in LDS laid out [level][thread] (conflict-free ds_read/write_b32).
+//     Result = min over accepted triangles with an order-independent tie rule, so it does not depend
+//     on the tree (the reference's own tree is random, mesh.cpp:171-172).
+//   * Shadow rays keep the reference's closest-hit + identity test (pathtracer.cpp:522-526) but stop
+//     as soon as an accepted occluder strictly nearer than the light sample is found (same outcome).
+//   * RNG: PCG-RXS-M-XS-32 per path, keyed on (seed, pixel, sample) - never on lane/block/GPU.
+//
+// Float arithmetic is written operation by operation in the reference's order and this file is
+// compiled with -ffp-contract=off: results are reproducible against the CPU oracle bit for bit.
+
+#include "ptk_device.h"
+
+namespace ptk {
+
+#define PTK_EPS 0.00001f                        // mesh.h:12
+#define PTK_FLT_EPSILON 1.1920928955078125e-7f
+#define PTK_PI_D 3.14159265358979323846
+#define PTK_BLOCK 256
+#define PTK_NOHIT 0x7fffffff
+
+struct v3 { float x, y, z; };
+
+__device__ __forceinline__ v3 V(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 mulv(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ v3 muls(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ v3 neg(v3 a) { return V(-a.x, -a.y, -a.z); }
+// glm 0.9.3.1 dot / cross / normalize / reflect (include/glm/core/func_geometric.inl:161-283)
+__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ v3 cross(v3 x, v3 y)
+{
+    return V(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+__device__ __forceinline__ v3 normalize(v3 a)
+{
+    float sqr = a.x * a.x + a.y * a.y + a.z * a.z;
+    float inv = 1.0f / sqrtf(sqr);
+    return muls(a, inv);
+}
+__device__ __forceinline__ v3 reflect(v3 I, v3 N)
+{
+    float d = dot(N, I);
+    return sub(I, muls(muls(N, d), 2.0f));
+}
+
+// sin/cos on [0, 2*pi]: fixed polynomial shared (by construction, not by source) with the oracle
+__device__ __forceinline__ void sincos_2pi(float a, float& s, float& c)
+{
+    int k = (int)(a * 0.636619772367581343f + 0.5f);
+    float r = (float)((double)a - (double)k * 1.57079632679489661923);
+    float z = r * r;
+    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
+               - 0.5f * z + 1.0f;
+    int q = k & 3;
+    float ss = (q & 1) ? cp : sp;
+    float cc = (q & 1) ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = (q == 1 || q == 2) ? -cc : cc;
+}
+
+// ---- RNG (replaces PathTracer::Rand, pathtracer.cpp:367-371) -----------------------------------
+__device__ __forceinline__ uint32_t pcg_out(uint32_t st)
+{
+    uint32_t w = ((st >> ((st >> 28u) + 4u)) ^ st) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+__device__ __forceinline__ uint32_t hash32(uint32_t x) { return pcg_out(x * 747796405u + 2891336453u); }
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-8f; }
+
+struct Rng {
+    uint32_t state, inc, key;
+    __device__ __forceinline__ float next()
+    {
+        uint32_t old = state;
+        state = old * 747796405u + inc;
+        return u01(pcg_out(old));
+    }
+    __device__ __forceinline__ float opacity(uint32_t ray, uint32_t tri) const
+    {
+        return u01(hash32(tri + hash32(ray + key)));
+    }
+};
+
+__device__ __forceinline__ float4 ldg4(const float4* p) { return *p; }
+
+// ---- Image::tex2D (image.cpp:63-86), nearest + repeat, RGBA8 atlas -----------------------------------
+__device__ __forceinline__ float4 tex2d(const RenderParams& P, int tex, float uvx, float uvy)
+{
+    int4 ti = P.texinfo[tex];
+    float u = uvx - truncf(uvx);              // == fmodf(uvx, 1.0f), exact
+    float v = uvy - truncf(uvy);
+    if (u < 0.0f) u += 1.0f;
+    if (v < 0.0f) v += 1.0f;
+    int cx = (int)((float)ti.x * u);
+    int cy = (int)((float)ti.y * v);
+    cx = min(cx, ti.x - 1); cy = min(cy, ti.y - 1);
+    cx = max(cx, 0); cy = max(cy, 0);
+    uint32_t w = P.texels[(size_t)ti.z + (size_t)cy * (size_t)ti.x + (size_t)cx];
+    float4 r;
+    r.x = (float)(w & 255u) / 255.0f;
+    r.y = (float)((w >> 8) & 255u) / 255.0f;
+    r.z = (float)((w >> 16) & 255u) / 255.0f;
+    r.w = (float)(w >> 24) / 255.0f;
+    return r;
+}
+template <class PT>
+__device__ __forceinline__ float tex2d_r(const PT& P, int tex, float uvx, float uvy)
+{
+    int4 ti = P.texinfo[tex];
+    float u = uvx - truncf(uvx);
+    float v = uvy - truncf(uvy);
+    if (u < 0.0f) u += 1.0f;
+    if (v < 0.0f) v += 1.0f;
+    int cx = (int)((float)ti.x * u);
+    int cy = (int)((float)ti.y * v);
+    cx = min(cx, ti.x - 1); cy = min(cy, ti.y - 1);
+    cx = max(cx, 0); cy = max(cy, 0);
+    uint32_t w = P.texels[(size_t)ti.z + (size_t)cy * (size_t)ti.x + (size_t)cx];
+    return (float)(w & 255u) / 255.0f;
+}
+
+struct Hit { int tri; float t, u, v; };
+
+struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex; };
+
+// ---- closest hit (replaces the recursive PathTracer::Hit, pathtracer.cpp:411-492) ---------------------
+// stack: this thread's column of the block's LDS stack, element k at stack[k * PTK_BLOCK].
+// occl_tri >= 0 marks a shadow ray towards light triangle occl_tri whose sample lies at distance
+// ~occl_limit/(1-1e-4): any accepted hit on another triangle nearer than occl_limit decides the
+// DirectIllumimation test (pathtracer.cpp:522-526) and ends the walk; it is reported as that hit.
+template <bool STATS, class PT>
+__device__ __forceinline__ bool closest_hit(const PT& P, v3 ro, v3 rd, const Rng& rng, uint32_t ray,
+                                            int* stack, int occl_tri, float occl_limit, Hit& out, Counters& cnt)
+{
+    Hit best;
+    best.tri = PTK_NOHIT; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
+    if (P.num_nodes == 0) { out = best; return false; }
+    v3 inv = V(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    int sp = 0;
+    int node = 0;
+    if (STATS) cnt.rays++;
+    while (node != NODE_EXIT)
+    {
+        if (node >= 0)
+        {
+            const float4* np = P.nodes + (size_t)node * NODE_F4;
+            float4 q0 = ldg4(np), q1 = ldg4(np + 1), q2 = ldg4(np + 2), q3 = ldg4(np + 3);
+            if (STATS) cnt.nodes++;
+            // left box
+            float ax0 = (q0.x - ro.x) * inv.x, ax1 = (q0.w - ro.x) * inv.x;
+            float ay0 = (q0.y - ro.y) * inv.y, ay1 = (q1.x - ro.y) * inv.y;
+            float az0 = (q0.z - ro.z) * inv.z, az1 = (q1.y - ro.z) * inv.z;
+            float tnl = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+            float tfl = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+            // right box
+            float bx0 = (q1.z - ro.x) * inv.x, bx1 = (q2.y - ro.x) * inv.x;
+            float by0 = (q1.w - ro.y) * inv.y, by1 = (q2.z - ro.y) * inv.y;
+            float bz0 = (q2.x - ro.z) * inv.z, bz1 = (q2.w - ro.z) * inv.z;
+            float tnr = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
+            float tfr = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
+            bool hl = (tnl <= tfl * 1.0000004f) && (tfl >= 0.0f) && (tnl <= best.t);
+            bool hr = (tnr <= tfr * 1.0000004f) && (tfr >= 0.0f) && (tnr <= best.t);
+            int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+            if (hl && hr)
+            {
+                bool lfirst = tnl <= tnr;
+                int nearc = lfirst ? left : right;
+                int farc = lfirst ? right : left;
+                stack[sp * PTK_BLOCK] = farc;
+                sp++;
+                node = nearc;
+            }
+            else if (hl) node = left;
+            else if (hr) node = right;
+            else
+            {
+                if (sp == 0) node = NODE_EXIT;
+                else { sp--; node = stack[sp * PTK_BLOCK]; }
+            }
+        }
+        else
+        {
+            int code = ~node;
+            int first = code >> 3, count = (code & 7) + 1;
+            for (int k = 0; k < count; k++)
+            {
+                const float4* tp = P.tris + (size_t)(first + k) * TRI_F4;
+                float4 t0 = ldg4(tp), t1 = ldg4(tp + 1), t2 = ldg4(tp + 2);
+                if (STATS) cnt.tris++;
+                // Moeller-Trumbore, PathTracer::IntersectTriangle pathtracer.cpp:373-409
+                v3 v0 = V(t0.x, t0.y, t0.z);
+                v3 edge1 = V(t0.w, t1.x, t1.y);
+                v3 edge2 = V(t1.z, t1.w, t2.x);
+                v3 h = cross(rd, edge2);
+                float a = dot(edge1, h);
+                if (fabsf(a) < PTK_EPS) continue;
+                float f = 1.0f / a;
+                v3 s = sub(ro, v0);
+                float u = f * dot(s, h);
+                if (u < 0.0f || u > 1.0f) continue;
+                v3 q = cross(s, edge1);
+                float v = f * dot(rd, q);
+                if (v < 0.0f || u + v > 1.0f) continue;
+                float t = f * dot(edge2, q);
+                if (!(t > PTK_EPS)) continue;
+                int tri = __float_as_int(t2.y);
+                if (!(t < best.t || (t == best.t && tri < best.tri))) continue;
+                int otex = __float_as_int(t2.z);
+                if (otex >= 0)
+                {
+                    // stochastic opacity, pathtracer.cpp:469-476 (GetUV :533-536)
+                    const float4* sp4 = P.shade + (size_t)tri * SHADE_F4;
+                    float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
+                    float w = 1.0f - u - v;
+                    float ux = w * s1.x + u * s1.z + v * s2.x;
+                    float uy = w * s1.y + u * s1.w + v * s2.y;
+                    float op = tex2d_r(P, otex, ux, uy);
+                    if (STATS) cnt.tex++;
+                    if (!(rng.opacity(ray, (uint32_t)tri) < op)) continue;
+                }
+                best.tri = tri; best.t = t; best.u = u; best.v = v;
+                if (occl_tri >= 0 && tri != occl_tri && t < occl_limit) { sp = 0; break; }
+            }
+            if (sp == 0) node = NODE_EXIT;
+            else { sp--; node = stack[sp * PTK_BLOCK]; }
+        }
+    }
+    out = best;
+    return best.tri != PTK_NOHIT;
+}
+
+// hemisphere / lobe sampler, pathtracer.cpp:606-611 (:618-623 lobe form): see oracle sample_about()
+__device__ __forceinline__ v3 sample_about(v3 n_for_test, float thr, v3 basis_from, v3 pole, float w, float theta)
+{
+    v3 u = fabsf(n_for_test.x) < thr ? cross(V(1.0f, 0.0f, 0.0f), basis_from) : cross(V(1.0f, 1.0f, 1.0f), basis_from);
+    u = normalize(u);
+    v3 v = normalize(cross(u, basis_from));
+    float ang = (float)(2.0f * PTK_PI_D * theta);
+    float sn, cs;
+    sincos_2pi(ang, sn, cs);
+    v3 d = add(add(muls(u, w * cs), muls(v, w * sn)), muls(pole, sqrtf(1.0f - w * w)));
+    return normalize(d);
+}
+
+__device__ __forceinline__ uint32_t pixel_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t pixel)
+{
+    uint32_t a = hash32(seed_hi);
+    uint32_t b = hash32(seed_lo + a);
+    return hash32(pixel + b);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(PTK_BLOCK) void render_kernel(const RenderParams P)
+{
+    __shared__ int lds_stack[PTK_MAX_BVH_DEPTH * PTK_BLOCK];
+    if (P.exit_flag && *P.exit_flag) return;
+
+    const int tid = threadIdx.x;
+    int* stack = lds_stack + tid;
+    const int tile = blockIdx.x * P.world + P.rank;
+    if (tile >= P.num_tiles) return;
+    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int px = tx * PTK_TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * PTK_TILE + (wave >> 1) * 8 + (lane >> 3);     // row from the top (pathtracer.cpp:777)
+    const bool valid = px < P.width && py < P.height;
+
+    const size_t accidx = ((size_t)(P.height - 1 - py) * P.width + px) * 3;   // bottom-up (pathtracer.cpp:796)
+    v3 acc = V(0.0f, 0.0f, 0.0f);
+    v3 dir0 = V(0.0f, 0.0f, 1.0f);
+    uint32_t pkey = 0;
+    if (valid)
+    {
+        acc = V(P.accum[accidx], P.accum[accidx + 1], P.accum[accidx + 2]);
+        float4 d = P.primary[(size_t)py * P.width + px];
+        dir0 = V(d.x, d.y, d.z);
+        pkey = pixel_key(P.seed_lo, P.seed_hi, (uint32_t)(py * P.width + px));
+    }
+    const v3 camPos0 = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    const v3 camRight = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
+    const v3 camUp = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
+
+    Counters cnt = { 0, 0, 0, 0, 0, 0 };
+    Rng rng;
+    rng.inc = (hash32(pkey ^ 0x9E3779B9u) << 1) | 1u;
+    rng.state = 0; rng.key = 0;
+
+    // per-lane path state
+    v3 ro = camPos0, rd = dir0;
+    v3 L = V(0.0f, 0.0f, 0.0f), T = V(1.0f, 1.0f, 1.0f);
+    v3 Tdi = V(0.0f, 0.0f, 0.0f), nextDir = V(0.0f, 0.0f, 1.0f);
+    int depth = 0, iter = 0;
+    bool inside = false;
+    uint32_t ray = 0;
+    int shadow_tri = -1;           // >= 0: the pending ray is a shadow ray towards this light triangle
+    float shadow_limit = 0.0f;
+    uint32_t sample = 0;
+    bool alive = valid && P.spp > 0;
+    bool fresh = true;             // start a new path before tracing
+
+    while (alive)
+    {
+        if (fresh)
+        {
+            // camera ray with thin-lens DOF, pathtracer.cpp:785-791 + SampleCircle :734-739
+            rng.state = hash32(P.first_sample + sample + pkey);
+            rng.key = rng.state;
+            v3 focalPoint = add(camPos0, muls(dir0, P.focal_dist));
+            float r1 = rng.next(), r2 = rng.next();
+            float angle = (float)((double)r1 * 2. * PTK_PI_D);
+            float radius = sqrtf(r2);
+            float sn, cs;
+            sincos_2pi(angle, sn, cs);
+            float offx = (cs * radius) * P.aperture, offy = (sn * radius) * P.aperture;
+            ro = add(camPos0, add(muls(camRight, offx), muls(camUp, offy)));
+            rd = normalize(sub(focalPoint, ro));
+            L = V(0.0f, 0.0f, 0.0f); T = V(1.0f, 1.0f, 1.0f);
+            depth = 0; iter = 0; inside = false; ray = 0; shadow_tri = -1;
+            fresh = false;
+        }
+
+        Hit h;
+        bool hit = closest_hit<STATS>(P, ro, rd, rng, ray, stack, shadow_tri, shadow_limit, h, cnt);
+        ray++;
+
+        if (shadow_tri >= 0)
+        {
+            // DirectIllumimation visibility, pathtracer.cpp:522-526: lit unless something else is closest
+            if (STATS) cnt.shadow++;
+            if (!(hit && h.tri != shadow_tri)) L = add(L, Tdi);
+            shadow_tri = -1;
+            rd = nextDir;                                   // continue with the sampled bounce (same origin)
+            continue;
+        }
+
+        bool ended = !hit;                                  // :550 miss -> black
+        if (hit)
+        {
+            if (STATS) cnt.shaded++;
+            const float4* sp4 = P.shade + (size_t)h.tri * SHADE_F4;
+            float4 s0 = ldg4(sp4);
+            int mbits = __float_as_int(s0.w);
+            int matid = mbits & 0x7fffffff;
+            bool smoothing = mbits < 0;
+            const float4* mp = P.mats + (size_t)matid * MAT_F4;
+            float4 m0 = ldg4(mp), m3 = ldg4(mp + 3);
+            float4 m4f = ldg4(mp + 4), m5f = ldg4(mp + 5);
+            int tex_diffuse = __float_as_int(m4f.x), tex_normal = __float_as_int(m4f.y);
+            int tex_emiss = __float_as_int(m4f.z), tex_rough = __float_as_int(m4f.w);
+            int tex_metal = __float_as_int(m5f.x);
+            bool any_tex = __float_as_int(m5f.z) != 0;
+
+            v3 p = add(ro, muls(rd, h.t));                  // :553
+            float uvx = 0.0f, uvy = 0.0f;
+            if (any_tex)
+            {
+                float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
+                float w = 1.0f - h.u - h.v;                 // GetUV :533-536
+                uvx = w * s1.x + h.u * s1.z + h.v * s2.x;
+                uvy = w * s1.y + h.u * s1.w + h.v * s2.y;
+            }
+            v3 n = V(s0.x, s0.y, s0.z);
+            if (smoothing)                                  // :556, GetSmoothNormal :538-543
+            {
+                float4 s2 = ldg4(sp4 + 2), s3 = ldg4(sp4 + 3), s4 = ldg4(sp4 + 4);
+                float w = 1.0f - h.u - h.v;
+                v3 n1 = V(s2.z, s2.w, s3.x), n2 = V(s3.y, s3.z, s3.w), n3 = V(s4.x, s4.y, s4.z);
+                v3 sn = add(add(muls(n1, w), muls(n2, h.u)), muls(n3, h.v));
+                n = normalize(sn);
+            }
+            if (tex_normal >= 0)                            // :558-566
+            {
+                float4 s4 = ldg4(sp4 + 4), s5 = ldg4(sp4 + 5), s6 = ldg4(sp4 + 6);
+                float4 c = tex2d(P, tex_normal, uvx, uvy);
+                if (STATS) cnt.tex++;
+                v3 nt = V(c.x * 2.0f - 1.0f, c.y * 2.0f - 1.0f, c.z * 2.0f - 1.0f);
+                if (nt.z <= 0.0f) nt = V(nt.x, nt.y, PTK_EPS);
+                nt = normalize(nt);
+                v3 tg = V(s4.w, s5.x, s5.y), bt = V(s5.z, s5.w, s6.x);
+                v3 m = V(tg.x * nt.x + bt.x * nt.y + n.x * nt.z,
+                         tg.y * nt.x + bt.y * nt.y + n.y * nt.z,
+                         tg.z * nt.x + bt.z * nt.y + n.z * nt.z);
+                n = normalize(m);
+            }
+            if (dot(n, rd) > 0.0f) n = neg(n);              // :567-568
+            p = add(p, muls(n, PTK_EPS));                   // :569
+
+            if (!(iter < P.max_depth)) ended = true;        // :571 terminal bounce: no emission
+            else
+            {
+                float4 m1 = ldg4(mp + 1), m2 = ldg4(mp + 2);
+                v3 diffuse = V(m0.x, m0.y, m0.z);
+                if (tex_diffuse >= 0) { float4 c = tex2d(P, tex_diffuse, uvx, uvy); diffuse = V(c.x, c.y, c.z); if (STATS) cnt.tex++; }
+                v3 emiss = V(m2.x, m2.y, m2.z);
+                if (tex_emiss >= 0) { float4 c = tex2d(P, tex_emiss, uvx, uvy); emiss = V(c.x, c.y, c.z); if (STATS) cnt.tex++; }
+                float roughness = m2.w;
+                if (tex_rough >= 0) { roughness = tex2d_r(P, tex_rough, uvx, uvy); if (STATS) cnt.tex++; }
+                float reflectiveness = m3.x;
+                if (tex_metal >= 0) { reflectiveness = tex2d_r(P, tex_metal, uvx, uvy); if (STATS) cnt.tex++; }
+                const int mtype = __float_as_int(m0.w);
+                const v3 specular = V(m1.x, m1.y, m1.z);
+                const float emissI = m1.w;
+
+                depth++; iter++;                            // :586-587
+                const float prob = m3.w;                    // min(0.95, max(diffuse)) of the constant colour
+                bool killed = false;
+                if (depth >= P.max_depth)
+                {
+                    if (fabsf(rng.next()) > prob) killed = true;    // :590-594, no 1/prob compensation
+                }
+                if (killed) ended = true;
+                else
+                {
+                    v3 r = reflect(rd, n);                  // :596
+                    v3 dir;
+                    v3 weight;
+                    bool diffuse_bounce = false;
+                    if (mtype == 0)
+                    {
+                        if (rng.next() < reflectiveness)    // :601
+                        {
+                            if (roughness == 1.0f) { float w = rng.next(), th = rng.next(); dir = sample_about(n, 1.0f - PTK_EPS, n, n, w, th); }
+                            else if (roughness == 0.0f) dir = r;
+                            else { float w = rng.next() * roughness, th = rng.next(); dir = sample_about(n, 1.0f - PTK_FLT_EPSILON, r, r, w, th); }
+                            iter--;
+                            weight = specular;              // :626
+                        }
+                        else
+                        {
+                            float w = rng.next(), th = rng.next();
+                            dir = sample_about(n, 1.0f - PTK_EPS, n, n, w, th);   // :631-636
+                            diffuse_bounce = true;
+                            weight = diffuse;               // :638
+                        }
+                    }
+                    else
+                    {
+                        bool refract = false;
+                        v3 refractN = n;
+                        if (roughness != 0.0f)              // :645-654
+                        {
+                            float w = rng.next() * roughness, th = rng.next();
+                            refractN = sample_about(n, 1.0f - PTK_FLT_EPSILON, r, n, w, th);
+                        }
+                        float nc = 1.0f, ng = m3.z;
+                        float eta = inside ? ng / nc : nc / ng;     // :658
+                        float r0 = (nc - ng) / (nc + ng);
+                        r0 = r0 * r0;
+                        float c = fabsf(dot(rd, refractN));
+                        float k = 1.0f - eta * eta * (1.0f - c * c);
+                        if (k < 0.0f) refract = false;
+                        else
+                        {
+                            float re = r0 + (1.0f - r0) * (1.0f - c) * (1.0f - c);    // :668
+                            if (fabsf(rng.next()) < re) refract = false;
+                            else if (rng.next() < reflectiveness) refract = false;
+                            else refract = true;
+                        }
+                        if (!refract)
+                        {
+                            if (roughness == 1.0f) { float w = rng.next(), th = rng.next(); dir = sample_about(n, 1.0f - PTK_EPS, n, n, w, th); }
+                            else if (roughness == 0.0f) dir = r;
+                            else { float w = rng.next() * roughness, th = rng.next(); dir = sample_about(n, 1.0f - PTK_FLT_EPSILON, r, r, w, th); }
+                            iter--;
+                            weight = specular;              // :702
+                        }
+                        else if (rng.next() < m3.y)         // :706 translucency
+                        {
+                            float a = eta * dot(n, rd) + sqrtf(k);
+                            dir = normalize(sub(muls(rd, eta), muls(refractN, a)));   // :708
+                            p = sub(p, muls(muls(n, PTK_EPS), 2.0f));                  // :709
+                            inside = !inside;
+                            iter--;
+                            weight = diffuse;               // :712
+                        }
+                        else
+                        {
+                            float w = rng.next(), th = rng.next();
+                            dir = sample_about(n, 1.0f - PTK_EPS, n, n, w, th);       // :717-722
+                            diffuse_bounce = true;
+                            weight = diffuse;               // :724
+                        }
+                    }
+
+                    L = add(L, mulv(T, muls(emiss, emissI)));      // emiss * emissiveIntensity term
+                    ro = p;
+                    rd = dir;
+                    if (diffuse_bounce && P.num_lights > 0)
+                    {
+                        // DirectIllumimation + SampleTriangle, pathtracer.cpp:494-531
+                        int lightId = (int)floorf(rng.next() * (float)P.num_lights);
+                        if (lightId == P.num_lights && lightId > 0) lightId--;
+                        const float4* lp = P.lights + (size_t)lightId * LIGHT_F4;
+                        float4 l0 = ldg4(lp), l1 = ldg4(lp + 1), l2 = ldg4(lp + 2), l3 = ldg4(lp + 3);
+                        float su = sqrtf(rng.next());
+                        float sv = rng.next();
+                        float w0 = 1.0f - su, w1 = su * (1.0f - sv), w2 = su * sv;
+                        v3 vLight = add(add(muls(V(l0.x, l0.y, l0.z), w0), muls(V(l1.x, l1.y, l1.z), w1)),
+                                        muls(V(l2.x, l2.y, l2.z), w2));
+                        v3 dl = sub(vLight, p);
+                        v3 l = normalize(dl);
+                        float ndl = dot(neg(n), neg(l));
+                        if (ndl > 0.0f)
+                        {
+                            v3 lColor = V(l1.w, l2.w, l3.x);
+                            v3 di = muls(mulv(lColor, diffuse), ndl);      // :530
+                            Tdi = mulv(T, di);
+                            shadow_tri = __float_as_int(l0.w);
+                            shadow_limit = sqrtf(dot(dl, dl)) * 0.9999f;
+                            nextDir = dir;
+                            rd = l;
+                        }
+                    }
+                    T = mulv(T, weight);
+                }
+            }
+        }
+
+        if (ended)
+        {
+            acc = add(acc, L);                              // :798-800
+            sample++;
+            if (sample < P.spp) fresh = true;
+            else alive = false;
+        }
+    }
+
+    if (valid)
+    {
+        P.accum[accidx] = acc.x; P.accum[accidx + 1] = acc.y; P.accum[accidx + 2] = acc.z;
+        // 8-bit resolve, pathtracer.cpp:802-812: clamp(total / samples) * 255, truncated
+        float c[3] = { acc.x / P.resolve_samples, acc.y / P.resolve_samples, acc.z / P.resolve_samples };
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+            float x = c[k];
+            x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+            if (!(x == x)) x = 0.0f;
+            P.rgb8[accidx + k] = (uint8_t)(x * 255);
+        }
+    }
+    if (STATS)
+    {
+        atomicAdd(&P.stats[0], (unsigned long long)(valid ? P.spp : 0));
+        atomicAdd(&P.stats[1], (unsigned long long)cnt.rays);
+        atomicAdd(&P.stats[2], (unsigned long long)cnt.shadow);
+        atomicAdd(&P.stats[3], (unsigned long long)cnt.nodes);
+        atomicAdd(&P.stats[4], (unsigned long long)cnt.tris);
+        atomicAdd(&P.stats[5], (unsigned long long)cnt.shaded);
+        atomicAdd(&P.stats[6], (unsigned long long)cnt.tex);
+    }
+}
+
+// Primary ray directions before DOF: one thread per image row walks the row with the reference's
+// incremental `pixel += camRight * deltaX` (pathtracer.cpp:782-785, :814), so every direction is
+// the value the reference computes.  Runs once per camera / resolution change.
+__global__ void primary_dirs_kernel(const PrimaryParams P)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.height) return;
+    v3 up = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
+    v3 right = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
+    v3 pos = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    v3 pixel = sub(V(P.top_left[0], P.top_left[1], P.top_left[2]), muls(up, (float)i * P.delta_y));
+    v3 step = muls(right, P.delta_x);
+    float4* row = P.primary + (size_t)i * P.width;
+    for (int j = 0; j < P.width; j++)
+    {
+        v3 d = normalize(sub(pixel, pos));
+        row[j] = make_float4(d.x, d.y, d.z, 0.0f);
+        pixel = add(pixel, step);
+    }
+}
+
+// Parity probe: closest hit for a list of rays (no opacity draws differ: key 0, ray 0).
+__global__ __launch_bounds__(PTK_BLOCK) void probe_hits_kernel(const ProbeParams P)
+{
+    __shared__ int lds_stack[PTK_MAX_BVH_DEPTH * PTK_BLOCK];
+    int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (i >= P.n) return;
+    Rng rng; rng.inc = (hash32(0u ^ 0x9E3779B9u) << 1) | 1u; rng.state = hash32(0u); rng.key = rng.state;
+    Counters cnt = { 0, 0, 0, 0, 0, 0 };
+    Hit h;
+    v3 ro = V(P.ro[i * 3], P.ro[i * 3 + 1], P.ro[i * 3 + 2]);
+    v3 rd = V(P.rd[i * 3], P.rd[i * 3 + 1], P.rd[i * 3 + 2]);
+    bool hit = closest_hit<false>(P, ro, rd, rng, 0u, lds_stack + threadIdx.x, -1, 0.0f, h, cnt);
+    P.tri[i] = hit ? h.tri : -1;
+    P.tuv[i * 3] = hit ? h.t : 0.0f; P.tuv[i * 3 + 1] = hit ? h.u : 0.0f; P.tuv[i * 3 + 2] = hit ? h.v : 0.0f;
+}
+
+void launch_render(const RenderParams& p, int blocks, hipStream_t stream, bool stats)
+{
+    if (blocks <= 0) return;
+    if (stats) hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(PTK_BLOCK), 0, stream, p);
+    else hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(PTK_BLOCK), 0, stream, p);
+}
+void launch_primary(const PrimaryParams& p, hipStream_t stream)
+{
+    int threads = 64;
+    hipLaunchKernelGGL(primary_dirs_kernel, dim3((p.height + threads - 1) / threads), dim3(threads), 0, stream, p);
+}
+void launch_probe(const ProbeParams& p, hipStream_t stream)
+{
+    if (p.n <= 0) return;
+    hipLaunchKernelGGL(probe_hits_kernel, dim3((p.n + PTK_BLOCK - 1) / PTK_BLOCK), dim3(PTK_BLOCK), 0, stream, p);
+}
+
+}  // namespace ptk

@@ -1,0 +1,249 @@
+"""ctypes binding of the ptk C-ABI (include/ptk.h) — the MI355X render path.
+
+There is NO CPU fallback here: if libptk.so (HIP kernels for gfx950 + host side) is missing or no
+GPU is visible, loading / creating a context raises.  Scenes are dicts of numpy arrays in the
+boundary's flat layout (see include/ptk.h `ptk_scene_desc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptk.so")
+
+PTK_OK = 0
+PTK_TILE = 16
+PTK_MAX_BVH_DEPTH = 32
+
+MATERIAL_DTYPE = np.dtype([
+    ("type", np.int32), ("diffuse", np.float32, 3), ("specular", np.float32, 3),
+    ("emissive", np.float32, 3), ("emissive_intensity", np.float32), ("roughness", np.float32),
+    ("reflectiveness", np.float32), ("translucency", np.float32), ("ior", np.float32),
+    ("tex", np.int32, 6)], align=False)
+TEXTURE_DTYPE = np.dtype([("width", np.int32), ("height", np.int32), ("offset", np.int64)])
+assert MATERIAL_DTYPE.itemsize == 84 and TEXTURE_DTYPE.itemsize == 16
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("num_triangles", C.c_int32), ("verts", C.c_void_p), ("normals", C.c_void_p),
+        ("uvs", C.c_void_p), ("tbn", C.c_void_p), ("smoothing", C.c_void_p), ("material", C.c_void_p),
+        ("num_materials", C.c_int32), ("materials", C.c_void_p),
+        ("num_textures", C.c_int32), ("textures", C.c_void_p), ("texels", C.c_void_p),
+        ("texel_bytes", C.c_int64),
+        ("num_lights", C.c_int32), ("lights", C.c_void_p),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in
+                ("samples", "rays", "shadow_rays", "node_visits", "tri_tests", "hits_shaded", "tex_fetches")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class PtkError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/ptk.h declares
+SYMBOLS = [
+    "ptk_create", "ptk_destroy", "ptk_upload_scene", "ptk_set_camera", "ptk_set_frame", "ptk_set_tile",
+    "ptk_reset", "ptk_render", "ptk_resolve_rgb8", "ptk_read_accum", "ptk_write_accum", "ptk_samples",
+    "ptk_request_exit", "ptk_synchronize", "ptk_last_error", "ptk_accum_device_ptr", "ptk_rgb8_device_ptr",
+    "ptk_bind_accum", "ptk_set_stream", "ptk_gather_accum", "ptk_last_render_ms", "ptk_collect_stats",
+    "ptk_bvh_info", "ptk_probe_hits", "ptk_probe_primary_dirs",
+]
+
+
+def load() -> C.CDLL:
+    """Load libptk.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PtkError(f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
+                       "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, u64, f32 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float
+    fp = C.POINTER(C.c_float)
+    L.ptk_create.argtypes = [C.POINTER(vp), i32]
+    L.ptk_destroy.argtypes = [vp]; L.ptk_destroy.restype = None
+    L.ptk_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.ptk_set_camera.argtypes = [vp, fp, fp, fp, f32, f32, f32, f32]
+    L.ptk_set_frame.argtypes = [vp, i32, i32, i32]
+    L.ptk_set_tile.argtypes = [vp, i32, i32]
+    L.ptk_reset.argtypes = [vp]
+    L.ptk_render.argtypes = [vp, u32, u32, u64]
+    L.ptk_resolve_rgb8.argtypes = [vp, vp]
+    L.ptk_read_accum.argtypes = [vp, vp]
+    L.ptk_write_accum.argtypes = [vp, vp, i32]
+    L.ptk_samples.argtypes = [vp]
+    L.ptk_request_exit.argtypes = [vp]
+    L.ptk_synchronize.argtypes = [vp]
+    L.ptk_last_error.argtypes = [vp]; L.ptk_last_error.restype = C.c_char_p
+    L.ptk_accum_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ptk_rgb8_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ptk_bind_accum.argtypes = [vp, vp]
+    L.ptk_set_stream.argtypes = [vp, vp]
+    L.ptk_gather_accum.argtypes = [vp, vp, i32]
+    L.ptk_last_render_ms.argtypes = [vp, fp, C.POINTER(i32)]
+    L.ptk_collect_stats.argtypes = [vp, u32, u32, u64, C.POINTER(Stats)]
+    L.ptk_bvh_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.ptk_probe_hits.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.ptk_probe_primary_dirs.argtypes = [vp, vp]
+    _lib = L
+    return L
+
+
+def normalise_arrays(a: dict) -> dict:
+    n = len(a["verts"])
+    return {
+        "verts": np.ascontiguousarray(a["verts"], dtype=np.float32).reshape(n, 9),
+        "normals": np.ascontiguousarray(a["normals"], dtype=np.float32).reshape(n, 9),
+        "uvs": np.ascontiguousarray(a["uvs"], dtype=np.float32).reshape(n, 6),
+        "tbn": np.ascontiguousarray(a["tbn"], dtype=np.float32).reshape(n, 9),
+        "smoothing": np.ascontiguousarray(a["smoothing"], dtype=np.uint8).reshape(n),
+        "material": np.ascontiguousarray(a["material"], dtype=np.int32).reshape(n),
+        "materials": np.ascontiguousarray(a["materials"], dtype=MATERIAL_DTYPE),
+        "textures": np.ascontiguousarray(a.get("textures", np.zeros(0, TEXTURE_DTYPE)), dtype=TEXTURE_DTYPE),
+        "texels": np.ascontiguousarray(a.get("texels", np.zeros(0, np.uint8)), dtype=np.uint8),
+        "lights": np.ascontiguousarray(a["lights"], dtype=np.int32),
+    }
+
+
+def scene_desc(a: dict) -> SceneDesc:
+    d = SceneDesc()
+    d.num_triangles = len(a["verts"])
+    for k in ("verts", "normals", "uvs", "tbn", "smoothing", "material", "materials", "textures", "texels", "lights"):
+        setattr(d, k, a[k].ctypes.data if a[k].size else None)
+    d.num_materials = len(a["materials"])
+    d.num_textures = len(a["textures"])
+    d.texel_bytes = a["texels"].size
+    d.num_lights = len(a["lights"])
+    return d
+
+
+class Context:
+    """One GPU, one HIP stream (ptk_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.ptk_create(C.byref(h), device)
+        if rc != PTK_OK:
+            raise PtkError(f"ptk_create(device={device}) failed with {rc}: no usable MI355X / HIP device")
+        self.h = h
+        self.width = self.height = 0
+        self._keep = None
+
+    def _chk(self, rc: int, what: str):
+        if rc != PTK_OK:
+            raise PtkError(f"{what} failed ({rc}): {self.L.ptk_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ptk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- scene / camera / frame ------------------------------------------------------------
+    def upload_scene(self, arrays: dict):
+        a = normalise_arrays(arrays)
+        d = scene_desc(a)
+        self._chk(self.L.ptk_upload_scene(self.h, C.byref(d)), "ptk_upload_scene")
+
+    def set_camera(self, pos, dir, up, focal, fovy, focal_dist, aperture):
+        f3 = C.c_float * 3
+        self._chk(self.L.ptk_set_camera(self.h, f3(*map(float, pos)), f3(*map(float, dir)), f3(*map(float, up)),
+                                        float(focal), float(fovy), float(focal_dist), float(aperture)), "ptk_set_camera")
+
+    def set_frame(self, width: int, height: int, max_depth: int):
+        self._chk(self.L.ptk_set_frame(self.h, width, height, max_depth), "ptk_set_frame")
+        self.width, self.height = width, height
+
+    def set_tile(self, rank: int, world: int):
+        self._chk(self.L.ptk_set_tile(self.h, rank, world), "ptk_set_tile")
+
+    def reset(self):
+        self._chk(self.L.ptk_reset(self.h), "ptk_reset")
+
+    # ---- render ----------------------------------------------------------------------------
+    def render(self, first_sample: int, spp: int, seed: int):
+        self._chk(self.L.ptk_render(self.h, first_sample, spp, seed), "ptk_render")
+
+    def synchronize(self):
+        self._chk(self.L.ptk_synchronize(self.h), "ptk_synchronize")
+
+    def read_accum(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._chk(self.L.ptk_read_accum(self.h, out.ctypes.data), "ptk_read_accum")
+        return out
+
+    def write_accum(self, total: np.ndarray, samples: int):
+        t = np.ascontiguousarray(total, dtype=np.float32)
+        assert t.shape == (self.height, self.width, 3)
+        self._chk(self.L.ptk_write_accum(self.h, t.ctypes.data, samples), "ptk_write_accum")
+
+    def resolve_rgb8(self, out: Optional[np.ndarray] = None) -> np.ndarray:
+        if out is None:
+            out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        self._chk(self.L.ptk_resolve_rgb8(self.h, out.ctypes.data), "ptk_resolve_rgb8")
+        return out
+
+    def samples(self) -> int:
+        return self.L.ptk_samples(self.h)
+
+    def request_exit(self):
+        self._chk(self.L.ptk_request_exit(self.h), "ptk_request_exit")
+
+    def last_render_ms(self):
+        ms = C.c_float(0); n = C.c_int(0)
+        self._chk(self.L.ptk_last_render_ms(self.h, C.byref(ms), C.byref(n)), "ptk_last_render_ms")
+        return ms.value, n.value
+
+    def collect_stats(self, first_sample: int, spp: int, seed: int) -> dict:
+        s = Stats()
+        self._chk(self.L.ptk_collect_stats(self.h, first_sample, spp, seed, C.byref(s)), "ptk_collect_stats")
+        return s.as_dict()
+
+    def bvh_info(self):
+        n = C.c_int32(); d = C.c_int32(); t = C.c_int32()
+        self._chk(self.L.ptk_bvh_info(self.h, C.byref(n), C.byref(d), C.byref(t)), "ptk_bvh_info")
+        return n.value, d.value, t.value
+
+    def accum_device_ptr(self):
+        p = C.c_void_p(); b = C.c_size_t()
+        self._chk(self.L.ptk_accum_device_ptr(self.h, C.byref(p), C.byref(b)), "ptk_accum_device_ptr")
+        return p.value, b.value
+
+    def bind_accum(self, dev_ptr: int):
+        self._chk(self.L.ptk_bind_accum(self.h, dev_ptr), "ptk_bind_accum")
+
+    def set_stream(self, stream_handle: int):
+        self._chk(self.L.ptk_set_stream(self.h, stream_handle), "ptk_set_stream")
+
+    # ---- probes ----------------------------------------------------------------------------
+    def probe_hits(self, ro: np.ndarray, rd: np.ndarray):
+        ro = np.ascontiguousarray(ro, np.float32); rd = np.ascontiguousarray(rd, np.float32)
+        n = len(ro)
+        tri = np.empty(n, np.int32); tuv = np.empty((n, 3), np.float32)
+        self._chk(self.L.ptk_probe_hits(self.h, n, ro.ctypes.data, rd.ctypes.data, tri.ctypes.data, tuv.ctypes.data), "ptk_probe_hits")
+        return tri, tuv
+
+    def primary_dirs(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), np.float32)
+        self._chk(self.L.ptk_probe_primary_dirs(self.h, out.ctypes.data), "ptk_probe_primary_dirs")
+        return out

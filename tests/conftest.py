@@ -1,0 +1,30 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def scene_from_golden(z):
+    return {k[6:]: z[k] for k in z.files if k.startswith("scene_")}
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle_binding as OB
+    OB.build()
+    return OB
