@@ -33,7 +33,7 @@ extern "C" {
 #define PTK_MAX_BVH_DEPTH 32     /* entries of the per-lane LDS traversal stack */
 
 /* replaces Material (mesh.h:21-59) with texture *indices* instead of Image pointers */
-typedef struct {
+typedef struct ptk_material {
     int32_t type;                /* 0 OPAQUE, 1 TRANSLUCENT (mesh.h:15-19) */
     float diffuse[3];
     float specular[3];
@@ -47,14 +47,14 @@ typedef struct {
 } ptk_material;                  /* 84 bytes, packed the same as the natural layout */
 
 /* replaces Image (image.h:7-28): RGBA8 texels live in one atlas */
-typedef struct {
+typedef struct ptk_texture {
     int32_t width, height;
     int64_t offset;              /* byte offset of this image's first texel in `texels` */
 } ptk_texture;
 
 /* replaces std::vector<Triangle> mTriangles + mLoadedObjects materials + mLights
  * (pathtracer.h:51-56; Triangle = mesh.h:71-96) as flat arrays */
-typedef struct {
+typedef struct ptk_scene_desc {
     int32_t num_triangles;
     const float* verts;          /* [N][9]  v1 v2 v3, world space */
     const float* normals;        /* [N][9]  n1 n2 n3 */
@@ -74,7 +74,7 @@ typedef struct {
 
 /* traversal statistics from the counters-enabled (untimed) kernel variant; feeds the
  * algorithmic-bytes roofline of SURVEY.md §8(d4) */
-typedef struct {
+typedef struct ptk_stats {
     uint64_t samples;            /* pixel*spp processed */
     uint64_t rays;               /* closest-hit traversals (bounce + shadow rays) */
     uint64_t shadow_rays;
