@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s (pixels x spp / s) of the per-pixel render loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--config C2] [--spp S]
+
+A "step" is one pass of the hot path over one batch: `spp` samples per pixel of the configured frame
+(default BASELINE.json configs[1]: Cornell box, 1280x720, 8 bounces, 256 spp), i.e. 256 RenderFrame()
+calls fused into one kernel launch, followed — for N > 1 — by the exchange step (sum-reduce of the
+float accumulator to rank 0 over RCCL).  The scene (replicated), the accumulator and the primary-ray
+table are resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), the frame
+is tile-split across ranks (16x16 tiles, round-robin), total work fixed -> "strong" scaling.
+
+Prints ONE JSON line on rank 0 (see the driver contract) including
+  roofline      algorithmic bytes per launch / measured kernel time vs the 8 TB/s HBM peak
+  cpu_baseline  the reference's own OpenMP CPU path (oracle/_ref, built from /root/reference by
+                __graft_entry__.build()) — or the oracle port if that .so is absent — timed on this
+                box's host cores on a bounded sample of the same workload (N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+# device record sizes (pbrpathtracer_amd/csrc/ptk_device.h) -> algorithmic bytes, DESIGN.md §Roofline
+BYTES_NODE = 64              # BVH2 node record: two child boxes + two child links
+BYTES_TRI = 48               # triangle intersection record: v0, e1, e2, ids
+BYTES_SHADE = 112            # shading record of the accepted hit
+BYTES_MATERIAL = 96
+BYTES_LIGHT = 64             # light record per shadow ray
+BYTES_TEXEL = 4
+BYTES_PIXEL_IO = 12 + 12 + 3 + 16   # accumulator read + write, RGB8 write, primary direction (per pixel per launch)
+
+
+def algorithmic_bytes_per_sample(stats: dict, spp: int) -> float:
+    s = float(stats["samples"])
+    return (BYTES_PIXEL_IO / float(spp)
+            + stats["node_visits"] / s * BYTES_NODE
+            + stats["tri_tests"] / s * BYTES_TRI
+            + stats["hits_shaded"] / s * (BYTES_SHADE + BYTES_MATERIAL)
+            + stats["shadow_rays"] / s * BYTES_LIGHT
+            + stats["tex_fetches"] / s * BYTES_TEXEL)
+
+
+def cpu_baseline(scene, name: str, budget_s: float = 12.0):
+    """Time the CPU path on a bounded sample of the same workload (whole frames of 1 spp)."""
+    from oracle import ref_binding
+    w, h = scene.width, scene.height
+    if ref_binding.available():
+        ref = ref_binding.Ref()
+        ref.load_scene(scene)
+        ref.lib.ref_seed(12345)
+        import ctypes
+        omp = ctypes.CDLL("libgomp.so.1")
+        maxt = omp.omp_get_max_threads()
+        workers = maxt - 3 if maxt > 2 else (maxt - 2 if maxt > 1 else maxt - 1)   # pathtracer.cpp:768-774
+        frames, sec = 0, 0.0
+        while sec < budget_s and frames < 64:
+            sec += ref.render(1, 0)
+            frames += 1
+        return {"value": round(w * h * frames / sec / 1e6, 4), "unit": "Msamples/s", "cores": int(workers), "kind": "reference",
+                "sample": f"{frames} RenderFrame() calls (1 spp each) of {name} at {w}x{h}, depth {scene.trace_depth}; "
+                          f"reference sources compiled -O2 -fopenmp, workers = omp_get_max_threads()-3, one shared mt19937"}
+    # fall back to the oracle port (our own C restatement), all cores, per-path counter RNG
+    from oracle import oracle_binding as OB
+    from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
+    pt = PathTracer()
+    pts = os.path.join(tempfile.mkdtemp(prefix="bench_cpu_"), "s.pts")
+    from pbrpathtracer_amd import scenes as S
+    S.write_pts(pts, scene)
+    pt.LoadSceneFile(pts)
+    arrays = pt.StagedScene()
+    cam = camera_from_scene(scene)
+    o = OB.Oracle(arrays)
+    ocam = OB.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+    cores = os.cpu_count() or 1
+    total = np.zeros((h, w, 3), np.float32)
+    frames, sec = 0, 0.0
+    while sec < budget_s and frames < 64:
+        t0 = time.time()
+        o.render(ocam, w, h, scene.trace_depth, frames, 1, 1, total=total, threads=cores, want_rgb8=False)
+        sec += time.time() - t0
+        frames += 1
+    return {"value": round(w * h * frames / sec / 1e6, 4), "unit": "Msamples/s", "cores": int(cores), "kind": "port",
+            "sample": f"{frames} frames (1 spp each) of {name} at {w}x{h}, depth {scene.trace_depth}; oracle/pt_oracle.c, OpenMP all cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (default: the config's spp)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+            sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer
+
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the render path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- scene: synthesised through the reference's own formats (.obj + .pts) ---------------------
+    tmp = tempfile.mkdtemp(prefix=f"bench_{args.config}_r{rank}_")
+    t0 = time.time()
+    pts, scene, cfg_spp = S.build_config(args.config, tmp)
+    spp = args.spp if args.spp > 0 else cfg_spp
+    t_gen = time.time() - t0
+    pt = PathTracer(device=local_rank)
+    t0 = time.time()
+    pt.LoadSceneFile(pts)                       # LoadObject/SetMaterial/.../BuildBVH/SetCamera/SetResolution
+    t_load = time.time() - t0
+    pt.SetSeed(args.seed)
+    pt.SetTile(rank, world)
+    W, H = pt.GetResolution()
+    D = pt.GetTraceDepth()
+    pt.RenderFrames(1)                          # creates the frame buffers, primary-ray table; 1 spp
+    if pt.LastError():
+        print("bench.py: " + pt.LastError(), file=sys.stderr)
+        sys.exit(3)
+    ctx = pt.context()
+    # the kernel renders into a torch-owned accumulator on torch's current stream, so the exchange
+    # step (torch.distributed -> RCCL) is ordered behind the render without host synchronisation
+    accum = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+    gathered = torch.zeros_like(accum) if world > 1 else None
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.bind_accum(accum.data_ptr())
+    ctx.reset()
+
+    def step(first):
+        ctx.render(first, spp, args.seed)
+        if world > 1:
+            gathered.copy_(accum)
+            dist.reduce(gathered, dst=0, op=dist.ReduceOp.SUM)     # tiles of other ranks are zero: a gather
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    first = 0
+    for _ in range(args.warmup):
+        step(first); first += spp
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(first); first += spp
+        if world == 1:
+            pass
+    fence()
+    elapsed = time.perf_counter() - t0
+    # per-launch kernel time measured with HIP events recorded on the kernel's own stream
+    ms_last, _ = ctx.last_render_ms()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel time per launch: replay `steps` launches individually with the event pair around each
+    ev_ms = []
+    for _ in range(min(args.steps, 5)):
+        ctx.render(first, spp, args.seed); first += spp
+        ms, _n = ctx.last_render_ms()
+        ev_ms.append(ms)
+    fence()
+
+    total_samples = float(W) * H * spp * args.steps
+    value = total_samples / elapsed / 1e6
+
+    out = None
+    if rank == 0:
+        # algorithmic bytes from the kernel's own traversal counts (untimed counters-enabled variant)
+        ctx.set_tile(0, 1)
+        stats = ctx.collect_stats(0, min(spp, 8), args.seed)
+        ctx.set_tile(rank, world)
+        bps = algorithmic_bytes_per_sample(stats, spp)
+        launch_samples = float(W) * H * spp / world
+        avg_ms = float(np.mean(ev_ms))
+        achieved = bps * launch_samples / (avg_ms * 1e-3) / 1e9
+        s = float(stats["samples"])
+        roofline = {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "render_kernel<false>", "kernel_ms": round(avg_ms, 4),
+            "algorithmic_bytes_per_sample": round(bps, 1),
+            "per_sample": {"rays": round(stats["rays"] / s, 3), "shadow_rays": round(stats["shadow_rays"] / s, 3),
+                           "node_visits": round(stats["node_visits"] / s, 2), "tri_tests": round(stats["tri_tests"] / s, 2),
+                           "hits_shaded": round(stats["hits_shaded"] / s, 3), "tex_fetches": round(stats["tex_fetches"] / s, 3)},
+            "note": "working set is cache-resident for this config: algorithmic bytes are served by L1/L2, not HBM",
+        }
+        traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file))
+                if tr.get("spp") == spp and tr.get("n_gpus", 1) == world:
+                    roofline["traffic"] = tr["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = tr.get("source")
+            except Exception:
+                pass
+        nodes, depth, ntri = ctx.bvh_info()
+        out = {
+            "metric": "Msamples/s (pixels*spp/s)", "value": round(value, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": {"C1": "Cornell box (12 tris), 512x512, 4 bounces, 16 spp",
+                                    "C2": "Cornell box (12 tris, no textures), 1280x720, 8 bounces, 256 spp",
+                                    "C3": "Textured PBR spheres + DOF, 1280x720, 8 bounces, 512 spp",
+                                    "C4": "bunny stand-in (~70k tris), 1920x1080, 8 bounces, 256 spp",
+                                    "C5": "1M-triangle height field, 1920x1080, 12 bounces, 1024 spp"}[args.config],
+                       "name": args.config, "width": W, "height": H, "max_depth": D, "spp_per_step": spp,
+                       "triangles": ntri, "bvh_nodes": nodes, "bvh_depth": depth,
+                       "parallelism": f"tile-split x{world}" if world > 1 else "single GPU",
+                       "exchange": "RCCL sum-reduce of the float accumulator to rank 0, once per step" if world > 1 else "none"},
+            "roofline": roofline,
+            "host": {"scene_gen_s": round(t_gen, 3), "scene_load_bvh_upload_s": round(t_load, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                # the CPU path is timed on the reference's own CPU-runnable shape of the same scene
+                base = cpu_baseline(scene, args.config)
+                out["cpu_baseline"] = base
+                out["gpu_over_cpu"] = round(value / base["value"], 1) if base["value"] > 0 else None
+            except Exception as e:  # the baseline is reported, never required
+                out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
