@@ -39,12 +39,14 @@ BYTES_SHADE = 112            # shading record of the accepted hit
 BYTES_MATERIAL = 96
 BYTES_LIGHT = 64             # light record per shadow ray
 BYTES_TEXEL = 4
-BYTES_PIXEL_IO = 12 + 12 + 3 + 16   # accumulator read + write, RGB8 write, primary direction (per pixel per launch)
+BYTES_SAMPLE_OUT = 16        # one float4 radiance sample stored per path (trace -> accumulate kernel)
+BYTES_PRIMARY = 16           # primary direction, fetched once per work item (chunk of samples)
 
 
-def algorithmic_bytes_per_sample(stats: dict, spp: int) -> float:
+def algorithmic_bytes_per_sample(stats: dict, chunk: int) -> float:
+    """trace_kernel: bytes one sample (one pixel x one spp) needs, from the kernel's own counts."""
     s = float(stats["samples"])
-    return (BYTES_PIXEL_IO / float(spp)
+    return (BYTES_SAMPLE_OUT + BYTES_PRIMARY / float(chunk)
             + stats["node_visits"] / s * BYTES_NODE
             + stats["tri_tests"] / s * BYTES_TRI
             + stats["hits_shaded"] / s * (BYTES_SHADE + BYTES_MATERIAL)
@@ -177,19 +179,18 @@ def main():
             pass
     fence()
     elapsed = time.perf_counter() - t0
-    # per-launch kernel time measured with HIP events recorded on the kernel's own stream
-    ms_last, _ = ctx.last_render_ms()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # kernel time per launch: replay `steps` launches individually with the event pair around each
-    ev_ms = []
+    # kernel time per launch, measured live with HIP events recorded on the kernels' own stream
+    # around each launch (trace_kernel and accumulate_kernel separately), over a few more steps
+    ev_ms, acc_ms = [], []
     for _ in range(min(args.steps, 5)):
         ctx.render(first, spp, args.seed); first += spp
-        ms, _n = ctx.last_render_ms()
-        ev_ms.append(ms)
+        t_ms, a_ms = ctx.last_kernel_ms()
+        ev_ms.append(t_ms); acc_ms.append(a_ms)
     fence()
 
     total_samples = float(W) * H * spp * args.steps
@@ -201,7 +202,8 @@ def main():
         ctx.set_tile(0, 1)
         stats = ctx.collect_stats(0, min(spp, 8), args.seed)
         ctx.set_tile(rank, world)
-        bps = algorithmic_bytes_per_sample(stats, spp)
+        chunk = min(spp, 32)
+        bps = algorithmic_bytes_per_sample(stats, chunk)
         launch_samples = float(W) * H * spp / world
         avg_ms = float(np.mean(ev_ms))
         achieved = bps * launch_samples / (avg_ms * 1e-3) / 1e9
@@ -209,7 +211,8 @@ def main():
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "render_kernel<false>", "kernel_ms": round(avg_ms, 4),
+            "kernel": "trace_kernel<false>", "kernel_ms": round(avg_ms, 4),
+            "accumulate_kernel_ms": round(float(np.mean(acc_ms)), 4),
             "algorithmic_bytes_per_sample": round(bps, 1),
             "per_sample": {"rays": round(stats["rays"] / s, 3), "shadow_rays": round(stats["shadow_rays"] / s, 3),
                            "node_visits": round(stats["node_visits"] / s, 2), "tri_tests": round(stats["tri_tests"] / s, 2),

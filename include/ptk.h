@@ -82,6 +82,10 @@ typedef struct ptk_stats {
     uint64_t tri_tests;          /* 48-byte triangle records fetched */
     uint64_t hits_shaded;        /* surface interactions shaded */
     uint64_t tex_fetches;        /* 4-byte texel fetches */
+    /* SIMD utilisation of the wave state machine: lanes that took part / (64 * wave-level executions) */
+    uint64_t walk_wave_iters, walk_lane_iters;     /* BVH-walk loop iterations per wave, and lanes active in them */
+    uint64_t shade_wave_execs, shade_lanes;        /* shading block executions per wave, lanes shaded */
+    uint64_t gen_wave_execs, gen_lanes;            /* camera-ray block executions per wave, lanes generated */
 } ptk_stats;
 
 typedef struct ptk_ctx ptk_ctx;
@@ -139,8 +143,13 @@ int ptk_set_stream(ptk_ctx* ctx, void* hip_stream);
  * (ncclComm_t passed as void*); tiles a rank does not own are zero, so the sum is a gather */
 int ptk_gather_accum(ptk_ctx* ctx, void* rccl_comm, int root);
 
-/* measurement */
-int ptk_last_render_ms(ptk_ctx* ctx, float* ms, int* launches);  /* HIP-event time of the last ptk_render's kernels */
+/* tuning: "chunk" = samples per work item (default 32), "pass_bytes" = HBM budget of the sample
+ * buffer between the trace and accumulate kernels (default 4 GiB).  Neither changes any result. */
+int ptk_set_option(ptk_ctx* ctx, const char* name, double value);
+
+/* measurement: HIP-event times (on the context's stream) of the last ptk_render's kernels */
+int ptk_last_render_ms(ptk_ctx* ctx, float* ms, int* launches);
+int ptk_last_kernel_ms(ptk_ctx* ctx, float* trace_ms, float* accumulate_ms);
 int ptk_collect_stats(ptk_ctx* ctx, uint32_t first_sample, uint32_t spp_count, uint64_t seed, ptk_stats* out);
 int ptk_bvh_info(ptk_ctx* ctx, int32_t* num_nodes, int32_t* depth, int32_t* num_leaf_tris);
 

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <limits>
@@ -12,7 +13,7 @@ namespace ptk {
 namespace {
 
 constexpr int kBins = 16;
-constexpr float kTravCost = 1.0f;   // one node record = two slab tests
+float kTravCost = 1.0f;             // one node record = two slab tests (PTK_TRAV_COST overrides, experiments)
 constexpr float kTriCost = 1.0f;
 
 struct Box {
@@ -180,6 +181,8 @@ bool build_bvh(const float* verts, int32_t n, int max_depth, int leaf_max, Built
 {
     out = BuiltBvh();
     if (n <= 0) return true;
+    if (const char* e = std::getenv("PTK_LEAF_MAX")) leaf_max = std::atoi(e);
+    if (const char* e = std::getenv("PTK_TRAV_COST")) kTravCost = (float)std::atof(e);
     if (leaf_max < 1) leaf_max = 1;
     if (leaf_max > 8) leaf_max = 8;
     if ((int64_t)n >= (1ll << 27)) return false;     // leaf code packs first << 3 into 31 bits
@@ -225,9 +228,11 @@ bool build_bvh(const float* verts, int32_t n, int max_depth, int leaf_max, Built
         out.nodes.assign(16, 0.0f);
         const TmpNode& L = B.nodes[root];
         float* q = out.nodes.data();
-        q[0] = L.box.mn[0]; q[1] = L.box.mn[1]; q[2] = L.box.mn[2]; q[3] = L.box.mx[0];
-        q[4] = L.box.mx[1]; q[5] = L.box.mx[2];
-        for (int k = 6; k < 12; k++) q[k] = qnan;
+        for (int a = 0; a < 3; a++)
+        {
+            q[2 * a] = L.box.mn[a]; q[2 * a + 1] = qnan;            // (left, right) plane pairs
+            q[6 + 2 * a] = L.box.mx[a]; q[6 + 2 * a + 1] = qnan;
+        }
         int32_t lc = leaf_code(L.first, L.count), rc = leaf_code(L.first, 1);
         std::memcpy(&q[12], &lc, 4); std::memcpy(&q[13], &rc, 4);
         out.num_nodes = 1; out.depth = 1;
@@ -252,9 +257,11 @@ bool build_bvh(const float* verts, int32_t n, int max_depth, int leaf_max, Built
             const TmpNode& L = B.nodes[N.left];
             const TmpNode& R = B.nodes[N.right];
             float* q = out.nodes.data() + (size_t)index[id] * 16;
-            q[0] = L.box.mn[0]; q[1] = L.box.mn[1]; q[2] = L.box.mn[2]; q[3] = L.box.mx[0];
-            q[4] = L.box.mx[1]; q[5] = L.box.mx[2]; q[6] = R.box.mn[0]; q[7] = R.box.mn[1];
-            q[8] = R.box.mn[2]; q[9] = R.box.mx[0]; q[10] = R.box.mx[1]; q[11] = R.box.mx[2];
+            for (int a = 0; a < 3; a++)
+            {
+                q[2 * a] = L.box.mn[a]; q[2 * a + 1] = R.box.mn[a];   // (left, right) plane pairs
+                q[6 + 2 * a] = L.box.mx[a]; q[6 + 2 * a + 1] = R.box.mx[a];
+            }
             int32_t lc = is_leaf(N.left) ? leaf_code(L.first, L.count) : index[N.left];
             int32_t rc = is_leaf(N.right) ? leaf_code(R.first, R.count) : index[N.right];
             std::memcpy(&q[12], &lc, 4); std::memcpy(&q[13], &rc, 4);

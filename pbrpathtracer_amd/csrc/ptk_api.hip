@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -52,7 +53,16 @@ struct ptk_ctx {
     uint32_t* d_exit = nullptr;
     unsigned long long* d_stats = nullptr;
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // sample buffer between trace_kernel and accumulate_kernel (grown on demand, never shrunk)
+    float4* d_samples = nullptr;
+    size_t samples_bytes = 0;
+    int opt_chunk = 16;                          // samples per work item
+    int opt_shade_thr = 48, opt_gen_thr = 48;    // see trace_kernel (1/64ths of the live lanes)
+    size_t opt_pass_bytes = (size_t)4 << 30;     // sample-buffer budget per pass
+
+    static constexpr int kMaxTimedPasses = 64;
+    hipEvent_t ev[kMaxTimedPasses][3] = {};      // per pass: before trace, after trace, after accumulate
+    int last_passes = 0;
     int last_launches = 0;
     bool timed = false;
 };
@@ -127,6 +137,8 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     std::memset(&p, 0, sizeof(p));
     p.nodes = c->d_nodes; p.tris = c->d_tris; p.shade = c->d_shade; p.mats = c->d_mats; p.lights = c->d_lights;
     p.texinfo = c->d_texinfo; p.texels = c->d_texels; p.primary = c->d_primary;
+    p.samples = c->d_samples;
+    p.shade_thr = c->opt_shade_thr; p.gen_thr = c->opt_gen_thr;
     p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.stats = c->d_stats;
     p.num_nodes = c->num_nodes; p.num_lights = c->num_lights;
     p.width = c->width; p.height = c->height; p.max_depth = c->max_depth;
@@ -140,11 +152,61 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     p.resolve_samples = (float)(first + spp);
 }
 
-int my_blocks(const RenderParams& p)
+int owned_tiles(const RenderParams& p)
 {
     // tiles t with t % world == rank
     if (p.num_tiles <= p.rank) return 0;
     return (p.num_tiles - p.rank + p.world - 1) / p.world;
+}
+
+// One pass = trace_kernel over (owned tiles x 4 quadrants x chunks) + accumulate_kernel.  The pass
+// size is bounded by the sample-buffer budget; chunk boundaries never change results (the RNG is
+// keyed on the absolute sample index and the accumulate kernel adds in sample order).
+int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool stats, float* accum, uint8_t* rgb8,
+               const uint32_t* exit_flag, bool timed)
+{
+    RenderParams p;
+    fill_params(c, p, first, spp, seed);
+    p.accum = accum; p.rgb8 = rgb8; p.exit_flag = exit_flag;
+    const int tiles = owned_tiles(p);
+    c->last_passes = 0; c->last_launches = 0;
+    if (tiles == 0) return PTK_OK;
+    const size_t per_sample = (size_t)tiles * 4 * 64 * sizeof(float4);
+    uint32_t max_pass = (uint32_t)std::max<size_t>(1, c->opt_pass_bytes / per_sample);
+    if (max_pass > (uint32_t)c->opt_chunk) max_pass -= max_pass % (uint32_t)c->opt_chunk;
+    uint32_t done = 0;
+    while (done < spp)
+    {
+        const uint32_t n = std::min(spp - done, max_pass);
+        const int chunk = (int)std::min<uint32_t>(n, (uint32_t)c->opt_chunk);
+        const int num_chunks = (int)((n + chunk - 1) / chunk);
+        const size_t need = per_sample * (size_t)chunk * num_chunks;
+        if (need > c->samples_bytes)
+        {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            dfree(c->d_samples); c->samples_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->d_samples, need));
+            c->samples_bytes = need;
+        }
+        p.samples = c->d_samples;
+        p.first_sample = first + done; p.spp = n;
+        p.chunk = chunk; p.num_chunks = num_chunks;
+        p.resolve_samples = (float)(first + done + n);
+        const long long items = (long long)tiles * 4 * num_chunks;
+        if (items > (1ll << 30)) return fail(c, PTK_ERR_LIMIT, "too many work items in one pass");
+        p.num_items = (int)items;
+        const int pi = c->last_passes < ptk_ctx::kMaxTimedPasses ? c->last_passes : -1;
+        if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][0], c->stream));
+        launch_trace(p, (int)items, c->stream, stats);
+        HIPCHK(c, hipGetLastError());
+        if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][1], c->stream));
+        launch_accumulate(p, tiles, c->stream);
+        HIPCHK(c, hipGetLastError());
+        if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][2], c->stream));
+        c->last_passes++; c->last_launches += 2;
+        done += n;
+    }
+    return PTK_OK;
 }
 
 }  // namespace
@@ -166,12 +228,14 @@ int ptk_create(ptk_ctx** out, int device_ordinal)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PTK_ERR_HIP; }
     c->own_stream = true;
     if (hipMalloc(&c->d_exit, sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_exit, 0, sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)
+        hipMalloc(&c->d_stats, 16 * sizeof(unsigned long long)) != hipSuccess)
     {
         ptk_destroy(c);
         return PTK_ERR_HIP;
     }
+    for (int i = 0; i < ptk_ctx::kMaxTimedPasses; i++)
+        for (int k = 0; k < 3; k++)
+            if (hipEventCreate(&c->ev[i][k]) != hipSuccess) { ptk_destroy(c); return PTK_ERR_HIP; }
     *out = c;
     return PTK_OK;
 }
@@ -183,9 +247,10 @@ void ptk_destroy(ptk_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_mats); dfree(c->d_lights);
     dfree(c->d_texinfo); dfree(c->d_texels); dfree(c->d_primary); dfree(c->d_accum); dfree(c->d_rgb8);
-    dfree(c->d_exit); dfree(c->d_stats);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    dfree(c->d_exit); dfree(c->d_stats); dfree(c->d_samples);
+    for (int i = 0; i < ptk_ctx::kMaxTimedPasses; i++)
+        for (int k = 0; k < 3; k++)
+            if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -435,14 +500,8 @@ int ptk_render(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uint64_t s
     }
     int rc = ensure_primary(c);
     if (rc != PTK_OK) return rc;
-    RenderParams p;
-    fill_params(c, p, first_sample, spp_count, seed);
-    int blocks = my_blocks(p);
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    launch_render(p, blocks, c->stream, false);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-    c->last_launches = blocks > 0 ? 1 : 0;
+    rc = run_passes(c, first_sample, spp_count, seed, false, accum_ptr(c), c->d_rgb8, c->d_exit, true);
+    if (rc != PTK_OK) return rc;
     c->timed = true;
     c->samples = (int)(first_sample + spp_count);
     return PTK_OK;
@@ -461,18 +520,19 @@ int ptk_collect_stats(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uin
     HIPCHK(c, hipMalloc(&scratch, px * 3 * sizeof(float)));
     if (hipMalloc(&scratch8, px * 3) != hipSuccess) { (void)hipFree(scratch); return fail(c, PTK_ERR_HIP, "hipMalloc"); }
     (void)hipMemsetAsync(scratch, 0, px * 3 * sizeof(float), c->stream);
-    (void)hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), c->stream);
-    RenderParams p;
-    fill_params(c, p, first_sample, spp_count, seed);
-    p.accum = scratch; p.rgb8 = scratch8; p.exit_flag = nullptr;
-    launch_render(p, my_blocks(p), c->stream, true);
-    unsigned long long h[8] = { 0 };
+    (void)hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), c->stream);
+    rc = run_passes(c, first_sample, spp_count, seed, true, scratch, scratch8, nullptr, false);
+    c->timed = false;
+    unsigned long long h[16] = { 0 };
     hipError_t e = hipMemcpyAsync(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(scratch); (void)hipFree(scratch8);
+    if (rc != PTK_OK) return rc;
     if (e != hipSuccess) return fail(c, PTK_ERR_HIP, hipGetErrorString(e));
     out->samples = h[0]; out->rays = h[1]; out->shadow_rays = h[2]; out->node_visits = h[3];
     out->tri_tests = h[4]; out->hits_shaded = h[5]; out->tex_fetches = h[6];
+    out->walk_wave_iters = h[7]; out->walk_lane_iters = h[8]; out->shade_wave_execs = h[9]; out->shade_lanes = h[10];
+    out->gen_wave_execs = h[11]; out->gen_lanes = h[12];
     return PTK_OK;
 }
 
@@ -569,13 +629,53 @@ int ptk_gather_accum(ptk_ctx* c, void* rccl_comm, int root)
 int ptk_last_render_ms(ptk_ctx* c, float* ms, int* launches)
 {
     if (!c || !ms) return PTK_ERR_BAD_ARG;
-    *ms = 0.0f;
+    float t = 0.0f, a = 0.0f;
+    int rc = ptk_last_kernel_ms(c, &t, &a);
+    *ms = t + a;
     if (launches) *launches = c->last_launches;
+    return rc;
+}
+
+int ptk_last_kernel_ms(ptk_ctx* c, float* trace_ms, float* accumulate_ms)
+{
+    if (!c || !trace_ms || !accumulate_ms) return PTK_ERR_BAD_ARG;
+    *trace_ms = 0.0f; *accumulate_ms = 0.0f;
     if (!c->timed) return PTK_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipEventSynchronize(c->ev1));
-    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    int n = std::min(c->last_passes, (int)ptk_ctx::kMaxTimedPasses);
+    for (int i = 0; i < n; i++)
+    {
+        float a = 0.0f, b = 0.0f;
+        HIPCHK(c, hipEventSynchronize(c->ev[i][2]));
+        HIPCHK(c, hipEventElapsedTime(&a, c->ev[i][0], c->ev[i][1]));
+        HIPCHK(c, hipEventElapsedTime(&b, c->ev[i][1], c->ev[i][2]));
+        *trace_ms += a; *accumulate_ms += b;
+    }
     return PTK_OK;
+}
+
+int ptk_set_option(ptk_ctx* c, const char* name, double value)
+{
+    if (!c || !name) return PTK_ERR_BAD_ARG;
+    if (!std::strcmp(name, "chunk"))
+    {
+        if (!(value >= 1 && value <= 4096)) return fail(c, PTK_ERR_BAD_ARG, "chunk must be in [1, 4096]");
+        c->opt_chunk = (int)value;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "shade_threshold") || !std::strcmp(name, "gen_threshold"))
+    {
+        if (!(value >= 1 && value <= 64)) return fail(c, PTK_ERR_BAD_ARG, "threshold must be in [1, 64] (64ths of a wave)");
+        (name[0] == 's' ? c->opt_shade_thr : c->opt_gen_thr) = (int)value;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "pass_bytes"))
+    {
+        if (!(value >= 1 << 20)) return fail(c, PTK_ERR_BAD_ARG, "pass_bytes must be >= 1 MiB");
+        c->opt_pass_bytes = (size_t)value;
+        return PTK_OK;
+    }
+    return fail(c, PTK_ERR_BAD_ARG, std::string("unknown option ") + name);
 }
 
 int ptk_bvh_info(ptk_ctx* c, int32_t* num_nodes, int32_t* depth, int32_t* num_leaf_tris)

@@ -10,9 +10,10 @@
 
 namespace ptk {
 
-// BVH2 node, 64 B: both child boxes live in the parent so one record feeds two slab tests.
-//   q0 = (lmin.x, lmin.y, lmin.z, lmax.x)   q1 = (lmax.y, lmax.z, rmin.x, rmin.y)
-//   q2 = (rmin.z, rmax.x, rmax.y, rmax.z)   q3 = (bits left, bits right, 0, 0)
+// BVH2 node, 64 B: both child boxes live in the parent so one record feeds two slab tests; the
+// planes of the left and right child are interleaved so each pair feeds one packed-f32 instruction.
+//   q0 = (lmin.x, rmin.x, lmin.y, rmin.y)   q1 = (lmin.z, rmin.z, lmax.x, rmax.x)
+//   q2 = (lmax.y, rmax.y, lmax.z, rmax.z)   q3 = (bits left, bits right, 0, 0)
 // child >= 0: interior node index; child < 0: leaf, ~child = (first_record << 3) | (count - 1)
 constexpr int NODE_F4 = 4;
 constexpr int LEAF_MAX = 8;
@@ -37,7 +38,17 @@ constexpr int MAT_F4 = 6;
 // with c = emissive * emissiveIntensity of the light's material (pathtracer.cpp:528)
 constexpr int LIGHT_F4 = 4;
 
+// Radiance samples travel from the trace kernel to the accumulate kernel through HBM:
+//   samples[(item * chunk + s) * 64 + lane] = (r, g, b, 0) of sample s of the item's chunk for the pixel
+//   of `lane`; item = (owned 16x16 tile * 4 + 8x8 quadrant) * num_chunks + chunk index.
+// The accumulate kernel folds them into the float accumulator strictly in sample order, which keeps
+// the reference's `mTotalImg[px] += color` once per RenderFrame() semantics (pathtracer.cpp:798-800)
+// while the tracing itself is parallel over pixels AND samples.
 struct RenderParams {
+    float4* samples;
+    int chunk, num_chunks;      // samples per work item, work items per 8x8 tile
+    int num_items;              // owned tiles * 4 * num_chunks
+    int shade_thr, gen_thr;     // state-machine thresholds in 1/64ths of a wave's live lanes
     const float4* nodes;
     const float4* tris;
     const float4* shade;
@@ -82,7 +93,8 @@ struct ProbeParams {
     int n, num_nodes;
 };
 
-void launch_render(const RenderParams& p, int blocks, hipStream_t stream, bool stats);
+void launch_trace(const RenderParams& p, int num_items, hipStream_t stream, bool stats);
+void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t stream);
 void launch_primary(const PrimaryParams& p, hipStream_t stream);
 void launch_probe(const ProbeParams& p, hipStream_t stream);
 

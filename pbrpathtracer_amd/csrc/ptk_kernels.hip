@@ -1,19 +1,31 @@
 // HIP kernels for gfx950 (CDNA4, wave64): the per-pixel render loop of the reference
 //   PathTracer::RenderFrame -> Trace -> Hit -> {IntersectTriangle, Image::tex2D, DirectIllumimation}
 //   (reference PathTracing/src/pathtracer.cpp:367-822, mesh.cpp:48-59, image.cpp:63-86)
-// as ONE megakernel: one path per lane, one 16x16 pixel tile per 256-thread block (four 8x8 waves).
+// as a path-tracing megakernel (trace_kernel: one path per lane, one 8x8 pixel tile x one chunk of
+// samples per wave) followed by a streaming accumulate_kernel.
 //
 // Design (not a translation of the reference's recursion):
 //   * Trace is iterative: L += T*e; L += T*direct; T *= weight, with the reference's two counters
 //     (depth arms Russian roulette, iter is the hard stop) and its quirks kept.
-//   * A lane is a small state machine {bounce ray, shadow ray}; bounce and shadow rays of different
-//     lanes share one traversal loop, and a lane whose path ends immediately starts the next sample
-//     of its pixel ("path regeneration"), so the wave stays full until the spp batch is done.  The
-//     float3 accumulator stays in registers for the whole batch: one read-modify-write per launch.
-//   * Closest hit: BVH2 with both child boxes in the 64-byte parent record, ordered descent with
-//     t-max culling, per-lane stack in LDS laid out [level][thread] (conflict-free ds_read/write_b32).
-//     Result = min over accepted triangles with an order-independent tie rule, so it does not depend
-//     on the tree (the reference's own tree is random, mesh.cpp:171-172).
+//   * Work item = (8x8 pixel tile, chunk of samples): parallel over pixels AND samples, so a frame
+//     with few non-trivial pixels still fills 256 CUs.  Each finished path stores its radiance as
+//     one float4 into a sample buffer in HBM; accumulate_kernel then folds the samples of a pixel
+//     into the float accumulator strictly in sample order (the reference's one-add-per-RenderFrame
+//     semantics, pathtracer.cpp:798-800) and writes the RGB8 resolve.
+//   * A lane is a state machine {GEN, TRAV, SHADE, DONE}.  Every wave iteration takes a 64-bit
+//     ballot per state and runs only the block most lanes are waiting for: the BVH walk keeps
+//     stepping while at least half of the live lanes are traversing (bounce and shadow rays share
+//     the walk; a finished shadow ray rolls straight into the bounce ray), shading / camera-ray
+//     generation run when enough lanes have queued up, and a lane whose path ends starts the next
+//     sample of its pixel ("path regeneration").  Divergent blocks therefore run with full-ish
+//     EXEC masks instead of once per ray.
+//   * Closest hit: BVH2 with both child boxes in the 64-byte parent record (left/right planes
+//     interleaved -> packed-f32 slab arithmetic), ordered descent with t-max culling, per-lane stack
+//     in LDS laid out [level][thread] (conflict-free ds_read/write_b32).  Result = min over accepted
+//     triangles with an order-independent tie rule, so it does not depend on the tree (the
+//     reference's own tree is random, mesh.cpp:171-172).  Box tests are acceleration only (any
+//     conservative test gives the same hit), so they use v_rcp and packed math; everything that
+//     reaches the image (Moeller-Trumbore, shading) is IEEE and in the reference's order.
 //   * Shadow rays keep the reference's closest-hit + identity test (pathtracer.cpp:522-526) but stop
 //     as soon as an accepted occluder strictly nearer than the light sample is found (same outcome).
 //   * RNG: PCG-RXS-M-XS-32 per path, keyed on (seed, pixel, sample) - never on lane/block/GPU.
@@ -29,6 +41,9 @@ namespace ptk {
 #define PTK_FLT_EPSILON 1.1920928955078125e-7f
 #define PTK_PI_D 3.14159265358979323846
 #define PTK_BLOCK 256
+#ifndef PTK_TRACE_BLOCK
+#define PTK_TRACE_BLOCK 64          // trace_kernel: one wave per workgroup -> finest-grained dispatch
+#endif
 #define PTK_NOHIT 0x7fffffff
 
 struct v3 { float x, y, z; };
@@ -97,6 +112,10 @@ struct Rng {
 };
 
 __device__ __forceinline__ float4 ldg4(const float4* p) { return *p; }
+typedef float f2 __attribute__((ext_vector_type(2)));
+// (float)byte / 255.0f, exactly: the double product rounds to the same float for all 256 bytes
+// (checked exhaustively in tests/test_host_cpu.py); saves the IEEE division sequence
+__device__ __forceinline__ float unorm8(uint32_t b) { return (float)((double)b * (1.0 / 255.0)); }
 
 // ---- Image::tex2D (image.cpp:63-86), nearest + repeat, RGBA8 atlas -----------------------------------
 __device__ __forceinline__ float4 tex2d(const RenderParams& P, int tex, float uvx, float uvy)
@@ -112,10 +131,10 @@ __device__ __forceinline__ float4 tex2d(const RenderParams& P, int tex, float uv
     cx = max(cx, 0); cy = max(cy, 0);
     uint32_t w = P.texels[(size_t)ti.z + (size_t)cy * (size_t)ti.x + (size_t)cx];
     float4 r;
-    r.x = (float)(w & 255u) / 255.0f;
-    r.y = (float)((w >> 8) & 255u) / 255.0f;
-    r.z = (float)((w >> 16) & 255u) / 255.0f;
-    r.w = (float)(w >> 24) / 255.0f;
+    r.x = unorm8(w & 255u);
+    r.y = unorm8((w >> 8) & 255u);
+    r.z = unorm8((w >> 16) & 255u);
+    r.w = unorm8(w >> 24);
     return r;
 }
 template <class PT>
@@ -131,117 +150,123 @@ __device__ __forceinline__ float tex2d_r(const PT& P, int tex, float uvx, float 
     cx = min(cx, ti.x - 1); cy = min(cy, ti.y - 1);
     cx = max(cx, 0); cy = max(cy, 0);
     uint32_t w = P.texels[(size_t)ti.z + (size_t)cy * (size_t)ti.x + (size_t)cx];
-    return (float)(w & 255u) / 255.0f;
+    return unorm8(w & 255u);
 }
 
 struct Hit { int tri; float t, u, v; };
 
-struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex; };
+struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex, walk_iters, walk_lanes, shade_execs, shade_lanes, gen_execs, gen_lanes; };
 
 // ---- closest hit (replaces the recursive PathTracer::Hit, pathtracer.cpp:411-492) ---------------------
-// stack: this thread's column of the block's LDS stack, element k at stack[k * PTK_BLOCK].
-// occl_tri >= 0 marks a shadow ray towards light triangle occl_tri whose sample lies at distance
-// ~occl_limit/(1-1e-4): any accepted hit on another triangle nearer than occl_limit decides the
-// DirectIllumimation test (pathtracer.cpp:522-526) and ends the walk; it is reported as that hit.
-template <bool STATS, class PT>
-__device__ __forceinline__ bool closest_hit(const PT& P, v3 ro, v3 rd, const Rng& rng, uint32_t ray,
-                                            int* stack, int occl_tri, float occl_limit, Hit& out, Counters& cnt)
-{
+// The walk is re-entrant: all of its state lives in this struct so a wave can interleave BVH steps
+// with shading of other lanes.  stack: this thread's column of the block's LDS stack, element k at
+// stack[k * PTK_BLOCK].
+struct Walk {
+    v3 ro, rd, inv;
+    int node, sp;
     Hit best;
-    best.tri = PTK_NOHIT; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
-    if (P.num_nodes == 0) { out = best; return false; }
-    v3 inv = V(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-    int sp = 0;
-    int node = 0;
-    if (STATS) cnt.rays++;
-    while (node != NODE_EXIT)
+    // occl_tri >= 0 marks a shadow ray towards light triangle occl_tri whose sample lies at distance
+    // ~occl_limit/(1-1e-4): any accepted hit on another triangle nearer than occl_limit decides the
+    // DirectIllumimation test (pathtracer.cpp:522-526) and ends the walk; it is reported as that hit.
+    int occl_tri;
+    float occl_limit;
+
+    __device__ __forceinline__ void begin(v3 o, v3 d, int num_nodes)
     {
-        if (node >= 0)
-        {
-            const float4* np = P.nodes + (size_t)node * NODE_F4;
-            float4 q0 = ldg4(np), q1 = ldg4(np + 1), q2 = ldg4(np + 2), q3 = ldg4(np + 3);
-            if (STATS) cnt.nodes++;
-            // left box
-            float ax0 = (q0.x - ro.x) * inv.x, ax1 = (q0.w - ro.x) * inv.x;
-            float ay0 = (q0.y - ro.y) * inv.y, ay1 = (q1.x - ro.y) * inv.y;
-            float az0 = (q0.z - ro.z) * inv.z, az1 = (q1.y - ro.z) * inv.z;
-            float tnl = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
-            float tfl = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
-            // right box
-            float bx0 = (q1.z - ro.x) * inv.x, bx1 = (q2.y - ro.x) * inv.x;
-            float by0 = (q1.w - ro.y) * inv.y, by1 = (q2.z - ro.y) * inv.y;
-            float bz0 = (q2.x - ro.z) * inv.z, bz1 = (q2.w - ro.z) * inv.z;
-            float tnr = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
-            float tfr = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
-            bool hl = (tnl <= tfl * 1.0000004f) && (tfl >= 0.0f) && (tnl <= best.t);
-            bool hr = (tnr <= tfr * 1.0000004f) && (tfr >= 0.0f) && (tnr <= best.t);
-            int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-            if (hl && hr)
-            {
-                bool lfirst = tnl <= tnr;
-                int nearc = lfirst ? left : right;
-                int farc = lfirst ? right : left;
-                stack[sp * PTK_BLOCK] = farc;
-                sp++;
-                node = nearc;
-            }
-            else if (hl) node = left;
-            else if (hr) node = right;
-            else
-            {
-                if (sp == 0) node = NODE_EXIT;
-                else { sp--; node = stack[sp * PTK_BLOCK]; }
-            }
-        }
-        else
-        {
-            int code = ~node;
-            int first = code >> 3, count = (code & 7) + 1;
-            for (int k = 0; k < count; k++)
-            {
-                const float4* tp = P.tris + (size_t)(first + k) * TRI_F4;
-                float4 t0 = ldg4(tp), t1 = ldg4(tp + 1), t2 = ldg4(tp + 2);
-                if (STATS) cnt.tris++;
-                // Moeller-Trumbore, PathTracer::IntersectTriangle pathtracer.cpp:373-409
-                v3 v0 = V(t0.x, t0.y, t0.z);
-                v3 edge1 = V(t0.w, t1.x, t1.y);
-                v3 edge2 = V(t1.z, t1.w, t2.x);
-                v3 h = cross(rd, edge2);
-                float a = dot(edge1, h);
-                if (fabsf(a) < PTK_EPS) continue;
-                float f = 1.0f / a;
-                v3 s = sub(ro, v0);
-                float u = f * dot(s, h);
-                if (u < 0.0f || u > 1.0f) continue;
-                v3 q = cross(s, edge1);
-                float v = f * dot(rd, q);
-                if (v < 0.0f || u + v > 1.0f) continue;
-                float t = f * dot(edge2, q);
-                if (!(t > PTK_EPS)) continue;
-                int tri = __float_as_int(t2.y);
-                if (!(t < best.t || (t == best.t && tri < best.tri))) continue;
-                int otex = __float_as_int(t2.z);
-                if (otex >= 0)
-                {
-                    // stochastic opacity, pathtracer.cpp:469-476 (GetUV :533-536)
-                    const float4* sp4 = P.shade + (size_t)tri * SHADE_F4;
-                    float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
-                    float w = 1.0f - u - v;
-                    float ux = w * s1.x + u * s1.z + v * s2.x;
-                    float uy = w * s1.y + u * s1.w + v * s2.y;
-                    float op = tex2d_r(P, otex, ux, uy);
-                    if (STATS) cnt.tex++;
-                    if (!(rng.opacity(ray, (uint32_t)tri) < op)) continue;
-                }
-                best.tri = tri; best.t = t; best.u = u; best.v = v;
-                if (occl_tri >= 0 && tri != occl_tri && t < occl_limit) { sp = 0; break; }
-            }
-            if (sp == 0) node = NODE_EXIT;
-            else { sp--; node = stack[sp * PTK_BLOCK]; }
-        }
+        ro = o; rd = d;
+        // acceleration only: 1-ulp reciprocals are fine for conservative slab tests
+        inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+        node = num_nodes > 0 ? 0 : NODE_EXIT;
+        sp = 0;
+        best.tri = PTK_NOHIT; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
     }
-    out = best;
-    return best.tri != PTK_NOHIT;
+    __device__ __forceinline__ bool done() const { return node == NODE_EXIT; }
+    template <int STRIDE>
+    __device__ __forceinline__ void pop(const int* stack)
+    {
+        if (sp == 0) node = NODE_EXIT;
+        else { sp--; node = stack[sp * STRIDE]; }
+    }
+};
+
+// one BVH step: an interior node (two slab tests) or a leaf (its triangles)
+template <bool STATS, int STRIDE, class PT>
+__device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, uint32_t ray, int* stack, Counters& cnt)
+{
+    if (W.node >= 0)
+    {
+        const float4* np = P.nodes + (size_t)W.node * NODE_F4;
+        float4 q0 = ldg4(np), q1 = ldg4(np + 1), q2 = ldg4(np + 2), q3 = ldg4(np + 3);
+        if (STATS) cnt.nodes++;
+        // (plane - origin) * inv for the left and right child at once (v_pk_add_f32 / v_pk_mul_f32)
+        f2 ox = { W.ro.x, W.ro.x }, oy = { W.ro.y, W.ro.y }, oz = { W.ro.z, W.ro.z };
+        f2 ix = { W.inv.x, W.inv.x }, iy = { W.inv.y, W.inv.y }, iz = { W.inv.z, W.inv.z };
+        f2 x0 = (f2{ q0.x, q0.y } - ox) * ix, y0 = (f2{ q0.z, q0.w } - oy) * iy, z0 = (f2{ q1.x, q1.y } - oz) * iz;
+        f2 x1 = (f2{ q1.z, q1.w } - ox) * ix, y1 = (f2{ q2.x, q2.y } - oy) * iy, z1 = (f2{ q2.z, q2.w } - oz) * iz;
+        float tnl = fmaxf(fmaxf(fminf(x0.x, x1.x), fminf(y0.x, y1.x)), fminf(z0.x, z1.x));
+        float tfl = fminf(fminf(fmaxf(x0.x, x1.x), fmaxf(y0.x, y1.x)), fmaxf(z0.x, z1.x));
+        float tnr = fmaxf(fmaxf(fminf(x0.y, x1.y), fminf(y0.y, y1.y)), fminf(z0.y, z1.y));
+        float tfr = fminf(fminf(fmaxf(x0.y, x1.y), fmaxf(y0.y, y1.y)), fmaxf(z0.y, z1.y));
+        bool hl = (tnl <= tfl * 1.000001f) && (tfl >= 0.0f) && (tnl <= W.best.t);
+        bool hr = (tnr <= tfr * 1.000001f) && (tfr >= 0.0f) && (tnr <= W.best.t);
+        int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+        if (hl && hr)
+        {
+            bool lfirst = tnl <= tnr;
+            stack[W.sp * STRIDE] = lfirst ? right : left;
+            W.sp++;
+            W.node = lfirst ? left : right;
+        }
+        else if (hl) W.node = left;
+        else if (hr) W.node = right;
+        else W.template pop<STRIDE>(stack);
+    }
+    else
+    {
+        int code = ~W.node;
+        int first = code >> 3, count = (code & 7) + 1;
+        const v3 ro = W.ro, rd = W.rd;
+        for (int k = 0; k < count; k++)
+        {
+            const float4* tp = P.tris + (size_t)(first + k) * TRI_F4;
+            float4 t0 = ldg4(tp), t1 = ldg4(tp + 1), t2 = ldg4(tp + 2);
+            if (STATS) cnt.tris++;
+            // Moeller-Trumbore, PathTracer::IntersectTriangle pathtracer.cpp:373-409
+            v3 v0 = V(t0.x, t0.y, t0.z);
+            v3 edge1 = V(t0.w, t1.x, t1.y);
+            v3 edge2 = V(t1.z, t1.w, t2.x);
+            v3 h = cross(rd, edge2);
+            float a = dot(edge1, h);
+            if (fabsf(a) < PTK_EPS) continue;
+            float f = 1.0f / a;
+            v3 s = sub(ro, v0);
+            float u = f * dot(s, h);
+            if (u < 0.0f || u > 1.0f) continue;
+            v3 q = cross(s, edge1);
+            float v = f * dot(rd, q);
+            if (v < 0.0f || u + v > 1.0f) continue;
+            float t = f * dot(edge2, q);
+            if (!(t > PTK_EPS)) continue;
+            int tri = __float_as_int(t2.y);
+            if (!(t < W.best.t || (t == W.best.t && tri < W.best.tri))) continue;
+            int otex = __float_as_int(t2.z);
+            if (otex >= 0)
+            {
+                // stochastic opacity, pathtracer.cpp:469-476 (GetUV :533-536)
+                const float4* sp4 = P.shade + (size_t)tri * SHADE_F4;
+                float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
+                float w = 1.0f - u - v;
+                float ux = w * s1.x + u * s1.z + v * s2.x;
+                float uy = w * s1.y + u * s1.w + v * s2.y;
+                float op = tex2d_r(P, otex, ux, uy);
+                if (STATS) cnt.tex++;
+                if (!(rng.opacity(ray, (uint32_t)tri) < op)) continue;
+            }
+            W.best.tri = tri; W.best.t = t; W.best.u = u; W.best.v = v;
+            if (W.occl_tri >= 0 && tri != W.occl_tri && t < W.occl_limit) { W.sp = 0; break; }
+        }
+        W.template pop<STRIDE>(stack);
+    }
 }
 
 // hemisphere / lobe sampler, pathtracer.cpp:606-611 (:618-623 lobe form): see oracle sample_about()
@@ -264,29 +289,35 @@ __device__ __forceinline__ uint32_t pixel_key(uint32_t seed_lo, uint32_t seed_hi
     return hash32(pixel + b);
 }
 
+enum : int { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_DONE = 3 };
+
 template <bool STATS>
-__global__ __launch_bounds__(PTK_BLOCK) void render_kernel(const RenderParams P)
+__global__ __launch_bounds__(PTK_TRACE_BLOCK) void trace_kernel(const RenderParams P)
 {
-    __shared__ int lds_stack[PTK_MAX_BVH_DEPTH * PTK_BLOCK];
-    if (P.exit_flag && *P.exit_flag) return;
+    __shared__ int lds_stack[PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
+    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
 
     const int tid = threadIdx.x;
     int* stack = lds_stack + tid;
-    const int tile = blockIdx.x * P.world + P.rank;
-    if (tile >= P.num_tiles) return;
+    const int lane = tid & 63;
+    // work item of this WAVE: (owned 16x16 tile, 8x8 quadrant, chunk of samples)
+    const int item = blockIdx.x * (PTK_TRACE_BLOCK / 64) + (tid >> 6);
+    const int subtile = item / P.num_chunks, chunk_id = item - subtile * P.num_chunks;
+    const int owned = subtile >> 2, quad = subtile & 3;
+    const int tile = owned * P.world + P.rank;
+    if (tile >= P.num_tiles || item >= P.num_items) return;
     const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int px = tx * PTK_TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * PTK_TILE + (wave >> 1) * 8 + (lane >> 3);     // row from the top (pathtracer.cpp:777)
+    const int px = tx * PTK_TILE + (quad & 1) * 8 + (lane & 7);
+    const int py = ty * PTK_TILE + (quad >> 1) * 8 + (lane >> 3);     // row from the top (pathtracer.cpp:777)
     const bool valid = px < P.width && py < P.height;
+    const uint32_t s_begin = (uint32_t)chunk_id * (uint32_t)P.chunk;
+    const uint32_t s_count = min((uint32_t)P.chunk, P.spp - s_begin);  // host guarantees s_begin < spp
+    float4* out = P.samples + ((size_t)item * P.chunk) * 64 + lane;
 
-    const size_t accidx = ((size_t)(P.height - 1 - py) * P.width + px) * 3;   // bottom-up (pathtracer.cpp:796)
-    v3 acc = V(0.0f, 0.0f, 0.0f);
     v3 dir0 = V(0.0f, 0.0f, 1.0f);
     uint32_t pkey = 0;
     if (valid)
     {
-        acc = V(P.accum[accidx], P.accum[accidx + 1], P.accum[accidx + 2]);
         float4 d = P.primary[(size_t)py * P.width + px];
         dir0 = V(d.x, d.y, d.z);
         pkey = pixel_key(P.seed_lo, P.seed_hi, (uint32_t)(py * P.width + px));
@@ -295,274 +326,363 @@ __global__ __launch_bounds__(PTK_BLOCK) void render_kernel(const RenderParams P)
     const v3 camRight = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
     const v3 camUp = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Rng rng;
     rng.inc = (hash32(pkey ^ 0x9E3779B9u) << 1) | 1u;
     rng.state = 0; rng.key = 0;
 
     // per-lane path state
-    v3 ro = camPos0, rd = dir0;
+    Walk W;
+    W.begin(camPos0, dir0, 0);
+    W.occl_tri = -1; W.occl_limit = 0.0f;
     v3 L = V(0.0f, 0.0f, 0.0f), T = V(1.0f, 1.0f, 1.0f);
     v3 Tdi = V(0.0f, 0.0f, 0.0f), nextDir = V(0.0f, 0.0f, 1.0f);
     int depth = 0, iter = 0;
     bool inside = false;
     uint32_t ray = 0;
-    int shadow_tri = -1;           // >= 0: the pending ray is a shadow ray towards this light triangle
-    float shadow_limit = 0.0f;
-    uint32_t sample = 0;
-    bool alive = valid && P.spp > 0;
-    bool fresh = true;             // start a new path before tracing
+    uint32_t sample = 0;            // index inside this chunk
+    int st = (valid && s_count > 0) ? ST_GEN : ST_DONE;
 
-    while (alive)
+    // a finished path: its radiance goes to the sample buffer, the lane moves to its next sample
+#define PTK_FINISH_PATH()                                                                         \
+    do {                                                                                          \
+        out[(size_t)sample * 64] = make_float4(L.x, L.y, L.z, 0.0f);                               \
+        sample++;                                                                                 \
+        st = sample < s_count ? ST_GEN : ST_DONE;                                                 \
+    } while (0)
+
+    for (;;)
     {
-        if (fresh)
+        const unsigned long long m_trav = __ballot(st == ST_TRAV);
+        const unsigned long long m_shade = __ballot(st == ST_SHADE);
+        const unsigned long long m_gen = __ballot(st == ST_GEN);
+        const int n_trav = __popcll(m_trav), n_shade = __popcll(m_shade), n_gen = __popcll(m_gen);
+        const int n_live = n_trav + n_shade + n_gen;
+        if (n_live == 0) break;
+
+        // Block choice: shading is the expensive block, so it waits until shade_thr/64 of the
+        // live lanes have queued up (or nothing else can make progress); the walk otherwise keeps
+        // stepping, and camera-ray generation (cheap) runs when no lane is traversing.
+        const bool run_shade = n_shade * 64 >= n_live * P.shade_thr || (n_trav == 0 && n_gen == 0);
+        if (!run_shade && n_trav > 0 && (n_gen * 64 < n_live * P.gen_thr))
         {
-            // camera ray with thin-lens DOF, pathtracer.cpp:785-791 + SampleCircle :734-739
-            rng.state = hash32(P.first_sample + sample + pkey);
-            rng.key = rng.state;
-            v3 focalPoint = add(camPos0, muls(dir0, P.focal_dist));
-            float r1 = rng.next(), r2 = rng.next();
-            float angle = (float)((double)r1 * 2. * PTK_PI_D);
-            float radius = sqrtf(r2);
-            float sn, cs;
-            sincos_2pi(angle, sn, cs);
-            float offx = (cs * radius) * P.aperture, offy = (sn * radius) * P.aperture;
-            ro = add(camPos0, add(muls(camRight, offx), muls(camUp, offy)));
-            rd = normalize(sub(focalPoint, ro));
-            L = V(0.0f, 0.0f, 0.0f); T = V(1.0f, 1.0f, 1.0f);
-            depth = 0; iter = 0; inside = false; ray = 0; shadow_tri = -1;
-            fresh = false;
-        }
-
-        Hit h;
-        bool hit = closest_hit<STATS>(P, ro, rd, rng, ray, stack, shadow_tri, shadow_limit, h, cnt);
-        ray++;
-
-        if (shadow_tri >= 0)
-        {
-            // DirectIllumimation visibility, pathtracer.cpp:522-526: lit unless something else is closest
-            if (STATS) cnt.shadow++;
-            if (!(hit && h.tri != shadow_tri)) L = add(L, Tdi);
-            shadow_tri = -1;
-            rd = nextDir;                                   // continue with the sampled bounce (same origin)
-            continue;
-        }
-
-        bool ended = !hit;                                  // :550 miss -> black
-        if (hit)
-        {
-            if (STATS) cnt.shaded++;
-            const float4* sp4 = P.shade + (size_t)h.tri * SHADE_F4;
-            float4 s0 = ldg4(sp4);
-            int mbits = __float_as_int(s0.w);
-            int matid = mbits & 0x7fffffff;
-            bool smoothing = mbits < 0;
-            const float4* mp = P.mats + (size_t)matid * MAT_F4;
-            float4 m0 = ldg4(mp), m3 = ldg4(mp + 3);
-            float4 m4f = ldg4(mp + 4), m5f = ldg4(mp + 5);
-            int tex_diffuse = __float_as_int(m4f.x), tex_normal = __float_as_int(m4f.y);
-            int tex_emiss = __float_as_int(m4f.z), tex_rough = __float_as_int(m4f.w);
-            int tex_metal = __float_as_int(m5f.x);
-            bool any_tex = __float_as_int(m5f.z) != 0;
-
-            v3 p = add(ro, muls(rd, h.t));                  // :553
-            float uvx = 0.0f, uvy = 0.0f;
-            if (any_tex)
+            // ---- BVH walk: keep stepping while at least half of the live lanes are traversing ----
+            do
             {
-                float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
-                float w = 1.0f - h.u - h.v;                 // GetUV :533-536
-                uvx = w * s1.x + h.u * s1.z + h.v * s2.x;
-                uvy = w * s1.y + h.u * s1.w + h.v * s2.y;
-            }
-            v3 n = V(s0.x, s0.y, s0.z);
-            if (smoothing)                                  // :556, GetSmoothNormal :538-543
-            {
-                float4 s2 = ldg4(sp4 + 2), s3 = ldg4(sp4 + 3), s4 = ldg4(sp4 + 4);
-                float w = 1.0f - h.u - h.v;
-                v3 n1 = V(s2.z, s2.w, s3.x), n2 = V(s3.y, s3.z, s3.w), n3 = V(s4.x, s4.y, s4.z);
-                v3 sn = add(add(muls(n1, w), muls(n2, h.u)), muls(n3, h.v));
-                n = normalize(sn);
-            }
-            if (tex_normal >= 0)                            // :558-566
-            {
-                float4 s4 = ldg4(sp4 + 4), s5 = ldg4(sp4 + 5), s6 = ldg4(sp4 + 6);
-                float4 c = tex2d(P, tex_normal, uvx, uvy);
-                if (STATS) cnt.tex++;
-                v3 nt = V(c.x * 2.0f - 1.0f, c.y * 2.0f - 1.0f, c.z * 2.0f - 1.0f);
-                if (nt.z <= 0.0f) nt = V(nt.x, nt.y, PTK_EPS);
-                nt = normalize(nt);
-                v3 tg = V(s4.w, s5.x, s5.y), bt = V(s5.z, s5.w, s6.x);
-                v3 m = V(tg.x * nt.x + bt.x * nt.y + n.x * nt.z,
-                         tg.y * nt.x + bt.y * nt.y + n.y * nt.z,
-                         tg.z * nt.x + bt.z * nt.y + n.z * nt.z);
-                n = normalize(m);
-            }
-            if (dot(n, rd) > 0.0f) n = neg(n);              // :567-568
-            p = add(p, muls(n, PTK_EPS));                   // :569
-
-            if (!(iter < P.max_depth)) ended = true;        // :571 terminal bounce: no emission
-            else
-            {
-                float4 m1 = ldg4(mp + 1), m2 = ldg4(mp + 2);
-                v3 diffuse = V(m0.x, m0.y, m0.z);
-                if (tex_diffuse >= 0) { float4 c = tex2d(P, tex_diffuse, uvx, uvy); diffuse = V(c.x, c.y, c.z); if (STATS) cnt.tex++; }
-                v3 emiss = V(m2.x, m2.y, m2.z);
-                if (tex_emiss >= 0) { float4 c = tex2d(P, tex_emiss, uvx, uvy); emiss = V(c.x, c.y, c.z); if (STATS) cnt.tex++; }
-                float roughness = m2.w;
-                if (tex_rough >= 0) { roughness = tex2d_r(P, tex_rough, uvx, uvy); if (STATS) cnt.tex++; }
-                float reflectiveness = m3.x;
-                if (tex_metal >= 0) { reflectiveness = tex2d_r(P, tex_metal, uvx, uvy); if (STATS) cnt.tex++; }
-                const int mtype = __float_as_int(m0.w);
-                const v3 specular = V(m1.x, m1.y, m1.z);
-                const float emissI = m1.w;
-
-                depth++; iter++;                            // :586-587
-                const float prob = m3.w;                    // min(0.95, max(diffuse)) of the constant colour
-                bool killed = false;
-                if (depth >= P.max_depth)
+                if (STATS) { const uint32_t nt = (uint32_t)__popcll(__ballot(st == ST_TRAV)); if (lane == 0) { cnt.walk_iters++; cnt.walk_lanes += nt; } }
+                if (st == ST_TRAV)
                 {
-                    if (fabsf(rng.next()) > prob) killed = true;    // :590-594, no 1/prob compensation
+                    walk_step<STATS, PTK_TRACE_BLOCK>(P, W, rng, ray, stack, cnt);
+                    if (W.done())
+                    {
+                        if (STATS) cnt.rays++;
+                        ray++;
+                        const bool hit = W.best.tri != PTK_NOHIT;
+                        if (W.occl_tri >= 0)
+                        {
+                            // DirectIllumimation visibility, pathtracer.cpp:522-526: lit unless something
+                            // else is closest; then continue with the sampled bounce from the same origin
+                            if (STATS) cnt.shadow++;
+                            if (!(hit && W.best.tri != W.occl_tri)) L = add(L, Tdi);
+                            W.occl_tri = -1;
+                            W.begin(W.ro, nextDir, P.num_nodes);
+                        }
+                        else if (!hit) PTK_FINISH_PATH();              // :550 miss -> black
+                        else st = ST_SHADE;
+                    }
                 }
-                if (killed) ended = true;
+                const int nt = __popcll(__ballot(st == ST_TRAV));
+                const int ns = __popcll(__ballot(st == ST_SHADE));
+                if (nt == 0 || ns * 64 >= n_live * P.shade_thr) break;
+                if ((n_live - nt - ns) * 64 >= n_live * P.gen_thr) break;
+            } while (true);
+        }
+        else if (run_shade)
+        {
+            if (STATS && lane == 0) { cnt.shade_execs++; cnt.shade_lanes += (uint32_t)n_shade; }
+            if (st == ST_SHADE)
+            {
+                // ---- one surface interaction of PathTracer::Trace, pathtracer.cpp:551-727 ----
+                const Hit h = W.best;
+                const v3 ro = W.ro, rd = W.rd;
+                if (STATS) cnt.shaded++;
+                const float4* sp4 = P.shade + (size_t)h.tri * SHADE_F4;
+                float4 s0 = ldg4(sp4);
+                int mbits = __float_as_int(s0.w);
+                int matid = mbits & 0x7fffffff;
+                bool smoothing = mbits < 0;
+                const float4* mp = P.mats + (size_t)matid * MAT_F4;
+                float4 m0 = ldg4(mp), m3 = ldg4(mp + 3);
+                float4 m4f = ldg4(mp + 4), m5f = ldg4(mp + 5);
+                int tex_diffuse = __float_as_int(m4f.x), tex_normal = __float_as_int(m4f.y);
+                int tex_emiss = __float_as_int(m4f.z), tex_rough = __float_as_int(m4f.w);
+                int tex_metal = __float_as_int(m5f.x);
+                bool any_tex = __float_as_int(m5f.z) != 0;
+
+                v3 p = add(ro, muls(rd, h.t));                  // :553
+                float uvx = 0.0f, uvy = 0.0f;
+                if (any_tex)
+                {
+                    float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
+                    float w = 1.0f - h.u - h.v;                 // GetUV :533-536
+                    uvx = w * s1.x + h.u * s1.z + h.v * s2.x;
+                    uvy = w * s1.y + h.u * s1.w + h.v * s2.y;
+                }
+                v3 n = V(s0.x, s0.y, s0.z);
+                if (smoothing)                                  // :556, GetSmoothNormal :538-543
+                {
+                    float4 s2 = ldg4(sp4 + 2), s3 = ldg4(sp4 + 3), s4 = ldg4(sp4 + 4);
+                    float w = 1.0f - h.u - h.v;
+                    v3 n1 = V(s2.z, s2.w, s3.x), n2 = V(s3.y, s3.z, s3.w), n3 = V(s4.x, s4.y, s4.z);
+                    v3 sn = add(add(muls(n1, w), muls(n2, h.u)), muls(n3, h.v));
+                    n = normalize(sn);
+                }
+                if (tex_normal >= 0)                            // :558-566
+                {
+                    float4 s4 = ldg4(sp4 + 4), s5 = ldg4(sp4 + 5), s6 = ldg4(sp4 + 6);
+                    float4 c = tex2d(P, tex_normal, uvx, uvy);
+                    if (STATS) cnt.tex++;
+                    v3 nt = V(c.x * 2.0f - 1.0f, c.y * 2.0f - 1.0f, c.z * 2.0f - 1.0f);
+                    if (nt.z <= 0.0f) nt = V(nt.x, nt.y, PTK_EPS);
+                    nt = normalize(nt);
+                    v3 tg = V(s4.w, s5.x, s5.y), bt = V(s5.z, s5.w, s6.x);
+                    v3 m = V(tg.x * nt.x + bt.x * nt.y + n.x * nt.z,
+                             tg.y * nt.x + bt.y * nt.y + n.y * nt.z,
+                             tg.z * nt.x + bt.z * nt.y + n.z * nt.z);
+                    n = normalize(m);
+                }
+                if (dot(n, rd) > 0.0f) n = neg(n);              // :567-568
+                p = add(p, muls(n, PTK_EPS));                   // :569
+
+                bool ended = false;
+                if (!(iter < P.max_depth)) ended = true;        // :571 terminal bounce: no emission
                 else
                 {
-                    v3 r = reflect(rd, n);                  // :596
-                    v3 dir;
-                    v3 weight;
-                    bool diffuse_bounce = false;
-                    if (mtype == 0)
-                    {
-                        if (rng.next() < reflectiveness)    // :601
-                        {
-                            if (roughness == 1.0f) { float w = rng.next(), th = rng.next(); dir = sample_about(n, 1.0f - PTK_EPS, n, n, w, th); }
-                            else if (roughness == 0.0f) dir = r;
-                            else { float w = rng.next() * roughness, th = rng.next(); dir = sample_about(n, 1.0f - PTK_FLT_EPSILON, r, r, w, th); }
-                            iter--;
-                            weight = specular;              // :626
-                        }
-                        else
-                        {
-                            float w = rng.next(), th = rng.next();
-                            dir = sample_about(n, 1.0f - PTK_EPS, n, n, w, th);   // :631-636
-                            diffuse_bounce = true;
-                            weight = diffuse;               // :638
-                        }
-                    }
-                    else
-                    {
-                        bool refract = false;
-                        v3 refractN = n;
-                        if (roughness != 0.0f)              // :645-654
-                        {
-                            float w = rng.next() * roughness, th = rng.next();
-                            refractN = sample_about(n, 1.0f - PTK_FLT_EPSILON, r, n, w, th);
-                        }
-                        float nc = 1.0f, ng = m3.z;
-                        float eta = inside ? ng / nc : nc / ng;     // :658
-                        float r0 = (nc - ng) / (nc + ng);
-                        r0 = r0 * r0;
-                        float c = fabsf(dot(rd, refractN));
-                        float k = 1.0f - eta * eta * (1.0f - c * c);
-                        if (k < 0.0f) refract = false;
-                        else
-                        {
-                            float re = r0 + (1.0f - r0) * (1.0f - c) * (1.0f - c);    // :668
-                            if (fabsf(rng.next()) < re) refract = false;
-                            else if (rng.next() < reflectiveness) refract = false;
-                            else refract = true;
-                        }
-                        if (!refract)
-                        {
-                            if (roughness == 1.0f) { float w = rng.next(), th = rng.next(); dir = sample_about(n, 1.0f - PTK_EPS, n, n, w, th); }
-                            else if (roughness == 0.0f) dir = r;
-                            else { float w = rng.next() * roughness, th = rng.next(); dir = sample_about(n, 1.0f - PTK_FLT_EPSILON, r, r, w, th); }
-                            iter--;
-                            weight = specular;              // :702
-                        }
-                        else if (rng.next() < m3.y)         // :706 translucency
-                        {
-                            float a = eta * dot(n, rd) + sqrtf(k);
-                            dir = normalize(sub(muls(rd, eta), muls(refractN, a)));   // :708
-                            p = sub(p, muls(muls(n, PTK_EPS), 2.0f));                  // :709
-                            inside = !inside;
-                            iter--;
-                            weight = diffuse;               // :712
-                        }
-                        else
-                        {
-                            float w = rng.next(), th = rng.next();
-                            dir = sample_about(n, 1.0f - PTK_EPS, n, n, w, th);       // :717-722
-                            diffuse_bounce = true;
-                            weight = diffuse;               // :724
-                        }
-                    }
+                    float4 m1 = ldg4(mp + 1), m2 = ldg4(mp + 2);
+                    v3 diffuse = V(m0.x, m0.y, m0.z);
+                    if (tex_diffuse >= 0) { float4 c = tex2d(P, tex_diffuse, uvx, uvy); diffuse = V(c.x, c.y, c.z); if (STATS) cnt.tex++; }
+                    v3 emiss = V(m2.x, m2.y, m2.z);
+                    if (tex_emiss >= 0) { float4 c = tex2d(P, tex_emiss, uvx, uvy); emiss = V(c.x, c.y, c.z); if (STATS) cnt.tex++; }
+                    float roughness = m2.w;
+                    if (tex_rough >= 0) { roughness = tex2d_r(P, tex_rough, uvx, uvy); if (STATS) cnt.tex++; }
+                    float reflectiveness = m3.x;
+                    if (tex_metal >= 0) { reflectiveness = tex2d_r(P, tex_metal, uvx, uvy); if (STATS) cnt.tex++; }
+                    const int mtype = __float_as_int(m0.w);
+                    const v3 specular = V(m1.x, m1.y, m1.z);
+                    const float emissI = m1.w;
 
-                    L = add(L, mulv(T, muls(emiss, emissI)));      // emiss * emissiveIntensity term
-                    ro = p;
-                    rd = dir;
-                    if (diffuse_bounce && P.num_lights > 0)
+                    depth++; iter++;                            // :586-587
+                    const float prob = m3.w;                    // min(0.95, max(diffuse)) of the constant colour
+                    if (depth >= P.max_depth)
                     {
-                        // DirectIllumimation + SampleTriangle, pathtracer.cpp:494-531
-                        int lightId = (int)floorf(rng.next() * (float)P.num_lights);
-                        if (lightId == P.num_lights && lightId > 0) lightId--;
-                        const float4* lp = P.lights + (size_t)lightId * LIGHT_F4;
-                        float4 l0 = ldg4(lp), l1 = ldg4(lp + 1), l2 = ldg4(lp + 2), l3 = ldg4(lp + 3);
-                        float su = sqrtf(rng.next());
-                        float sv = rng.next();
-                        float w0 = 1.0f - su, w1 = su * (1.0f - sv), w2 = su * sv;
-                        v3 vLight = add(add(muls(V(l0.x, l0.y, l0.z), w0), muls(V(l1.x, l1.y, l1.z), w1)),
-                                        muls(V(l2.x, l2.y, l2.z), w2));
-                        v3 dl = sub(vLight, p);
-                        v3 l = normalize(dl);
-                        float ndl = dot(neg(n), neg(l));
-                        if (ndl > 0.0f)
-                        {
-                            v3 lColor = V(l1.w, l2.w, l3.x);
-                            v3 di = muls(mulv(lColor, diffuse), ndl);      // :530
-                            Tdi = mulv(T, di);
-                            shadow_tri = __float_as_int(l0.w);
-                            shadow_limit = sqrtf(dot(dl, dl)) * 0.9999f;
-                            nextDir = dir;
-                            rd = l;
-                        }
+                        if (fabsf(rng.next()) > prob) ended = true;     // :590-594, no 1/prob compensation
                     }
-                    T = mulv(T, weight);
+                    if (!ended)
+                    {
+                        v3 r = reflect(rd, n);                  // :596
+                        v3 dir;
+                        v3 weight;
+                        bool diffuse_bounce = false;
+                        // the reference spells the same three-way roughness sampler out three times
+                        // (:603-624, :679-700) and the hemisphere sampler twice more (:631-636, :717-722);
+                        // here the branch only picks the sampler's arguments and ONE call does the work
+                        int sampler = 0;                        // 0: mirror direction r, 1: hemisphere about n, 2: lobe about r
+                        if (mtype == 0)
+                        {
+                            if (rng.next() < reflectiveness)    // :601
+                            {
+                                sampler = roughness == 1.0f ? 1 : (roughness == 0.0f ? 0 : 2);
+                                iter--;
+                                weight = specular;              // :626
+                            }
+                            else
+                            {
+                                sampler = 1;                    // :631-636
+                                diffuse_bounce = true;
+                                weight = diffuse;               // :638
+                            }
+                        }
+                        else
+                        {
+                            bool refract = false;
+                            v3 refractN = n;
+                            if (roughness != 0.0f)              // :645-654
+                            {
+                                float w = rng.next() * roughness, th = rng.next();
+                                refractN = sample_about(n, 1.0f - PTK_FLT_EPSILON, r, n, w, th);
+                            }
+                            float nc = 1.0f, ng = m3.z;
+                            float eta = inside ? ng / nc : nc / ng;     // :658
+                            float r0 = (nc - ng) / (nc + ng);
+                            r0 = r0 * r0;
+                            float c = fabsf(dot(rd, refractN));
+                            float k = 1.0f - eta * eta * (1.0f - c * c);
+                            if (k < 0.0f) refract = false;
+                            else
+                            {
+                                float re = r0 + (1.0f - r0) * (1.0f - c) * (1.0f - c);    // :668
+                                if (fabsf(rng.next()) < re) refract = false;
+                                else if (rng.next() < reflectiveness) refract = false;
+                                else refract = true;
+                            }
+                            if (!refract)
+                            {
+                                sampler = roughness == 1.0f ? 1 : (roughness == 0.0f ? 0 : 2);
+                                iter--;
+                                weight = specular;              // :702
+                            }
+                            else if (rng.next() < m3.y)         // :706 translucency
+                            {
+                                float a = eta * dot(n, rd) + sqrtf(k);
+                                dir = normalize(sub(muls(rd, eta), muls(refractN, a)));   // :708
+                                p = sub(p, muls(muls(n, PTK_EPS), 2.0f));                  // :709
+                                inside = !inside;
+                                iter--;
+                                weight = diffuse;               // :712
+                                sampler = 3;                    // direction already set
+                            }
+                            else
+                            {
+                                sampler = 1;                    // :717-722
+                                diffuse_bounce = true;
+                                weight = diffuse;               // :724
+                            }
+                        }
+                        if (sampler == 0) dir = r;
+                        else if (sampler != 3)
+                        {
+                            const bool lobe = sampler == 2;
+                            float w = rng.next();
+                            if (lobe) w = w * roughness;
+                            float th = rng.next();
+                            dir = sample_about(n, lobe ? 1.0f - PTK_FLT_EPSILON : 1.0f - PTK_EPS, lobe ? r : n, lobe ? r : n, w, th);
+                        }
+
+                        L = add(L, mulv(T, muls(emiss, emissI)));      // emiss * emissiveIntensity term
+                        v3 next_ro = p, next_rd = dir;
+                        if (diffuse_bounce && P.num_lights > 0)
+                        {
+                            // DirectIllumimation + SampleTriangle, pathtracer.cpp:494-531
+                            int lightId = (int)floorf(rng.next() * (float)P.num_lights);
+                            if (lightId == P.num_lights && lightId > 0) lightId--;
+                            const float4* lp = P.lights + (size_t)lightId * LIGHT_F4;
+                            float4 l0 = ldg4(lp), l1 = ldg4(lp + 1), l2 = ldg4(lp + 2), l3 = ldg4(lp + 3);
+                            float su = sqrtf(rng.next());
+                            float sv = rng.next();
+                            float w0 = 1.0f - su, w1 = su * (1.0f - sv), w2 = su * sv;
+                            v3 vLight = add(add(muls(V(l0.x, l0.y, l0.z), w0), muls(V(l1.x, l1.y, l1.z), w1)),
+                                            muls(V(l2.x, l2.y, l2.z), w2));
+                            v3 dl = sub(vLight, p);
+                            v3 l = normalize(dl);
+                            float ndl = dot(neg(n), neg(l));
+                            if (ndl > 0.0f)
+                            {
+                                v3 lColor = V(l1.w, l2.w, l3.x);
+                                v3 di = muls(mulv(lColor, diffuse), ndl);      // :530
+                                Tdi = mulv(T, di);
+                                W.occl_tri = __float_as_int(l0.w);
+                                W.occl_limit = sqrtf(dot(dl, dl)) * 0.9999f;
+                                nextDir = dir;
+                                next_rd = l;
+                            }
+                        }
+                        T = mulv(T, weight);
+                        W.begin(next_ro, next_rd, P.num_nodes);
+                        st = ST_TRAV;
+                    }
                 }
+                if (ended) PTK_FINISH_PATH();
             }
         }
-
-        if (ended)
+        else
         {
-            acc = add(acc, L);                              // :798-800
-            sample++;
-            if (sample < P.spp) fresh = true;
-            else alive = false;
+            if (STATS && lane == 0) { cnt.gen_execs++; cnt.gen_lanes += (uint32_t)n_gen; }
+            if (st == ST_GEN)
+            {
+                // ---- camera ray with thin-lens DOF, pathtracer.cpp:785-791 + SampleCircle :734-739 ----
+                rng.state = hash32(P.first_sample + s_begin + sample + pkey);
+                rng.key = rng.state;
+                v3 focalPoint = add(camPos0, muls(dir0, P.focal_dist));
+                float r1 = rng.next(), r2 = rng.next();          // always two draws, even with a pinhole
+                v3 ro = camPos0;
+                if (P.aperture != 0.0f)
+                {
+                    float angle = (float)((double)r1 * 2. * PTK_PI_D);
+                    float radius = sqrtf(r2);
+                    float sn, cs;
+                    sincos_2pi(angle, sn, cs);
+                    float offx = (cs * radius) * P.aperture, offy = (sn * radius) * P.aperture;
+                    ro = add(camPos0, add(muls(camRight, offx), muls(camUp, offy)));
+                }
+                v3 rd = normalize(sub(focalPoint, ro));
+                L = V(0.0f, 0.0f, 0.0f); T = V(1.0f, 1.0f, 1.0f);
+                depth = 0; iter = 0; inside = false; ray = 0;
+                W.occl_tri = -1;
+                W.begin(ro, rd, P.num_nodes);
+                st = ST_TRAV;
+            }
         }
     }
+#undef PTK_FINISH_PATH
 
-    if (valid)
-    {
-        P.accum[accidx] = acc.x; P.accum[accidx + 1] = acc.y; P.accum[accidx + 2] = acc.z;
-        // 8-bit resolve, pathtracer.cpp:802-812: clamp(total / samples) * 255, truncated
-        float c[3] = { acc.x / P.resolve_samples, acc.y / P.resolve_samples, acc.z / P.resolve_samples };
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-        {
-            float x = c[k];
-            x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
-            if (!(x == x)) x = 0.0f;
-            P.rgb8[accidx + k] = (uint8_t)(x * 255);
-        }
-    }
     if (STATS)
     {
-        atomicAdd(&P.stats[0], (unsigned long long)(valid ? P.spp : 0));
+        atomicAdd(&P.stats[0], (unsigned long long)(valid ? s_count : 0));
         atomicAdd(&P.stats[1], (unsigned long long)cnt.rays);
         atomicAdd(&P.stats[2], (unsigned long long)cnt.shadow);
         atomicAdd(&P.stats[3], (unsigned long long)cnt.nodes);
         atomicAdd(&P.stats[4], (unsigned long long)cnt.tris);
         atomicAdd(&P.stats[5], (unsigned long long)cnt.shaded);
         atomicAdd(&P.stats[6], (unsigned long long)cnt.tex);
+        if (lane == 0)
+        {
+            atomicAdd(&P.stats[7], (unsigned long long)cnt.walk_iters);
+            atomicAdd(&P.stats[8], (unsigned long long)cnt.walk_lanes);
+            atomicAdd(&P.stats[9], (unsigned long long)cnt.shade_execs);
+            atomicAdd(&P.stats[10], (unsigned long long)cnt.shade_lanes);
+            atomicAdd(&P.stats[11], (unsigned long long)cnt.gen_execs);
+            atomicAdd(&P.stats[12], (unsigned long long)cnt.gen_lanes);
+        }
+    }
+}
+
+// Streaming fold of the sample buffer into the float accumulator, strictly in sample order
+// (`mTotalImg[px] += color` once per RenderFrame(), pathtracer.cpp:798-800), plus the 8-bit resolve
+// (pathtracer.cpp:802-812).  One thread per pixel; each sample read is a coalesced 1 KiB per wave.
+__global__ __launch_bounds__(PTK_BLOCK) void accumulate_kernel(const RenderParams P)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, quad = tid >> 6;
+    const int owned = blockIdx.x;
+    const int tile = owned * P.world + P.rank;
+    if (tile >= P.num_tiles) return;
+    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const int px = tx * PTK_TILE + (quad & 1) * 8 + (lane & 7);
+    const int py = ty * PTK_TILE + (quad >> 1) * 8 + (lane >> 3);
+    if (px >= P.width || py >= P.height) return;
+    const size_t accidx = ((size_t)(P.height - 1 - py) * P.width + px) * 3;   // bottom-up (pathtracer.cpp:796)
+    v3 acc = V(P.accum[accidx], P.accum[accidx + 1], P.accum[accidx + 2]);
+    const size_t subtile = (size_t)owned * 4 + quad;
+    for (int c = 0; c < P.num_chunks; c++)
+    {
+        const float4* in = P.samples + ((subtile * P.num_chunks + c) * P.chunk) * 64 + lane;
+        const uint32_t s_begin = (uint32_t)c * (uint32_t)P.chunk;
+        const uint32_t n = min((uint32_t)P.chunk, P.spp - s_begin);
+        for (uint32_t s = 0; s < n; s++)
+        {
+            float4 col = in[(size_t)s * 64];
+            acc = add(acc, V(col.x, col.y, col.z));
+        }
+    }
+    P.accum[accidx] = acc.x; P.accum[accidx + 1] = acc.y; P.accum[accidx + 2] = acc.z;
+    float c3[3] = { acc.x / P.resolve_samples, acc.y / P.resolve_samples, acc.z / P.resolve_samples };
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+    {
+        float x = c3[k];
+        x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+        if (!(x == x)) x = 0.0f;
+        P.rgb8[accidx + k] = (uint8_t)(x * 255);
     }
 }
 
@@ -594,20 +714,29 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_hits_kernel(const ProbeParams
     int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (i >= P.n) return;
     Rng rng; rng.inc = (hash32(0u ^ 0x9E3779B9u) << 1) | 1u; rng.state = hash32(0u); rng.key = rng.state;
-    Counters cnt = { 0, 0, 0, 0, 0, 0 };
-    Hit h;
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     v3 ro = V(P.ro[i * 3], P.ro[i * 3 + 1], P.ro[i * 3 + 2]);
     v3 rd = V(P.rd[i * 3], P.rd[i * 3 + 1], P.rd[i * 3 + 2]);
-    bool hit = closest_hit<false>(P, ro, rd, rng, 0u, lds_stack + threadIdx.x, -1, 0.0f, h, cnt);
-    P.tri[i] = hit ? h.tri : -1;
-    P.tuv[i * 3] = hit ? h.t : 0.0f; P.tuv[i * 3 + 1] = hit ? h.u : 0.0f; P.tuv[i * 3 + 2] = hit ? h.v : 0.0f;
+    Walk W;
+    W.occl_tri = -1; W.occl_limit = 0.0f;
+    W.begin(ro, rd, P.num_nodes);
+    while (!W.done()) walk_step<false, PTK_BLOCK>(P, W, rng, 0u, lds_stack + threadIdx.x, cnt);
+    bool hit = W.best.tri != PTK_NOHIT;
+    P.tri[i] = hit ? W.best.tri : -1;
+    P.tuv[i * 3] = hit ? W.best.t : 0.0f; P.tuv[i * 3 + 1] = hit ? W.best.u : 0.0f; P.tuv[i * 3 + 2] = hit ? W.best.v : 0.0f;
 }
 
-void launch_render(const RenderParams& p, int blocks, hipStream_t stream, bool stats)
+void launch_trace(const RenderParams& p, int num_items, hipStream_t stream, bool stats)
 {
-    if (blocks <= 0) return;
-    if (stats) hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(PTK_BLOCK), 0, stream, p);
-    else hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(PTK_BLOCK), 0, stream, p);
+    if (num_items <= 0) return;
+    int blocks = (num_items + (PTK_TRACE_BLOCK / 64) - 1) / (PTK_TRACE_BLOCK / 64);
+    if (stats) hipLaunchKernelGGL(trace_kernel<true>, dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+}
+void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t stream)
+{
+    if (owned_tiles <= 0) return;
+    hipLaunchKernelGGL(accumulate_kernel, dim3(owned_tiles), dim3(PTK_BLOCK), 0, stream, p);
 }
 void launch_primary(const PrimaryParams& p, hipStream_t stream)
 {

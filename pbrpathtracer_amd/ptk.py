@@ -41,7 +41,8 @@ class SceneDesc(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
-                ("samples", "rays", "shadow_rays", "node_visits", "tri_tests", "hits_shaded", "tex_fetches")]
+                ("samples", "rays", "shadow_rays", "node_visits", "tri_tests", "hits_shaded", "tex_fetches",
+                 "walk_wave_iters", "walk_lane_iters", "shade_wave_execs", "shade_lanes", "gen_wave_execs", "gen_lanes")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -58,7 +59,8 @@ SYMBOLS = [
     "ptk_create", "ptk_destroy", "ptk_upload_scene", "ptk_set_camera", "ptk_set_frame", "ptk_set_tile",
     "ptk_reset", "ptk_render", "ptk_resolve_rgb8", "ptk_read_accum", "ptk_write_accum", "ptk_samples",
     "ptk_request_exit", "ptk_synchronize", "ptk_last_error", "ptk_accum_device_ptr", "ptk_rgb8_device_ptr",
-    "ptk_bind_accum", "ptk_set_stream", "ptk_gather_accum", "ptk_last_render_ms", "ptk_collect_stats",
+    "ptk_bind_accum", "ptk_set_stream", "ptk_gather_accum", "ptk_set_option", "ptk_last_render_ms",
+    "ptk_last_kernel_ms", "ptk_collect_stats",
     "ptk_bvh_info", "ptk_probe_hits", "ptk_probe_primary_dirs",
 ]
 
@@ -95,6 +97,8 @@ def load() -> C.CDLL:
     L.ptk_set_stream.argtypes = [vp, vp]
     L.ptk_gather_accum.argtypes = [vp, vp, i32]
     L.ptk_last_render_ms.argtypes = [vp, fp, C.POINTER(i32)]
+    L.ptk_last_kernel_ms.argtypes = [vp, fp, fp]
+    L.ptk_set_option.argtypes = [vp, C.c_char_p, C.c_double]
     L.ptk_collect_stats.argtypes = [vp, u32, u32, u64, C.POINTER(Stats)]
     L.ptk_bvh_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ptk_probe_hits.argtypes = [vp, i32, vp, vp, vp, vp]
@@ -213,6 +217,14 @@ class Context:
         ms = C.c_float(0); n = C.c_int(0)
         self._chk(self.L.ptk_last_render_ms(self.h, C.byref(ms), C.byref(n)), "ptk_last_render_ms")
         return ms.value, n.value
+
+    def last_kernel_ms(self):
+        t = C.c_float(0); a = C.c_float(0)
+        self._chk(self.L.ptk_last_kernel_ms(self.h, C.byref(t), C.byref(a)), "ptk_last_kernel_ms")
+        return t.value, a.value
+
+    def set_option(self, name: str, value: float):
+        self._chk(self.L.ptk_set_option(self.h, name.encode(), float(value)), "ptk_set_option")
 
     def collect_stats(self, first_sample: int, spp: int, seed: int) -> dict:
         s = Stats()

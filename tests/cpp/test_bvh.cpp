@@ -27,7 +27,8 @@ static int check(const std::vector<float>& verts, int n, int max_depth, int leaf
         if (depth > max_depth + 1) { errors++; return; }
         const float* q = b.nodes.data() + (size_t)node * 16;
         int32_t child[2]; std::memcpy(child, q + 12, 8);
-        const float box[2][6] = { { q[0], q[1], q[2], q[3], q[4], q[5] }, { q[6], q[7], q[8], q[9], q[10], q[11] } };
+        // planes are stored as (left, right) pairs: min x, y, z then max x, y, z
+        const float box[2][6] = { { q[0], q[2], q[4], q[6], q[8], q[10] }, { q[1], q[3], q[5], q[7], q[9], q[11] } };
         for (int c = 0; c < 2; c++)
         {
             if (std::isnan(box[c][0])) continue;      // empty child
@@ -91,7 +92,7 @@ int main()
         int n = 4000; std::vector<float> v((size_t)n * 9);
         for (int i = 0; i < n; i++)
         {
-            float x = std::pow(1.02f, (float)i);
+            float x = std::pow(1.002f, (float)i);
             float tri[9] = { x, 0, 0, x * 1.001f, 1, 0, x * 1.001f, 0, 1 };
             std::memcpy(&v[(size_t)i * 9], tri, sizeof tri);
         }
