@@ -5,7 +5,7 @@
 
 A "step" is one pass of the hot path over one batch: `spp` samples per pixel of the configured frame
 (default BASELINE.json configs[1]: Cornell box, 1280x720, 8 bounces, 256 spp), i.e. 256 RenderFrame()
-calls fused into one kernel launch, followed — for N > 1 — by the exchange step (sum-reduce of the
+calls as one trace_kernel + one accumulate_kernel launch, followed — for N > 1 — by the exchange step (sum-reduce of the
 float accumulator to rank 0 over RCCL).  The scene (replicated), the accumulator and the primary-ray
 table are resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), the frame
 is tile-split across ranks (16x16 tiles, round-robin), total work fixed -> "strong" scaling.
@@ -156,11 +156,12 @@ def main():
     ctx.bind_accum(accum.data_ptr())
     ctx.reset()
 
+    from pbrpathtracer_amd.distributed import gather_accumulator
+
     def step(first):
         ctx.render(first, spp, args.seed)
         if world > 1:
-            gathered.copy_(accum)
-            dist.reduce(gathered, dst=0, op=dist.ReduceOp.SUM)     # tiles of other ranks are zero: a gather
+            gather_accumulator(accum, out=gathered, dst=0)         # tiles of other ranks are zero: a gather
 
     def fence():
         if world > 1:
@@ -202,7 +203,7 @@ def main():
         ctx.set_tile(0, 1)
         stats = ctx.collect_stats(0, min(spp, 8), args.seed)
         ctx.set_tile(rank, world)
-        chunk = min(spp, 32)
+        chunk = min(spp, 16)      # ptk default samples per work item
         bps = algorithmic_bytes_per_sample(stats, chunk)
         launch_samples = float(W) * H * spp / world
         avg_ms = float(np.mean(ev_ms))

@@ -1,0 +1,68 @@
+"""N > 1 path on CPU: world_size-2 gloo processes, each renders only its tiles (with the oracle standing
+in for the GPU), then the exchange step of pbrpathtracer_amd.distributed combines them.  Checks that the
+tile partition is disjoint and complete and that the reduced image equals the single-rank image bit for
+bit — the property the RCCL path relies on."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle_binding as OB
+    from pbrpathtracer_amd import distributed as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = np.load(os.path.join(GOLDEN, "tier_s_glass.npz"))
+    arrays = {k[6:]: z[k] for k in z.files if k.startswith("scene_")}
+    o = OB.Oracle(arrays)
+    cam = OB.make_camera(z["cam"][0:3], z["cam"][3:6], z["cam"][6:9], float(z["proj"][0]), float(z["proj"][1]),
+                         float(z["focal_dist"]), float(z["aperture"]))
+    W, H, Dp, spp = 70, 50, 5, 3
+    total, _ = o.render(cam, W, H, Dp, 0, spp, 9, rank=rank, world=world, threads=2, want_rgb8=False)
+    # ownership as the Python mirror predicts it (rows of `total` are bottom-up)
+    mask = D.tile_owner_mask(W, H, rank, world)[::-1]
+    assert not total[~mask].any()
+    local = torch.from_numpy(total.reshape(-1).copy())
+    out = D.gather_accumulator(local, dst=0)
+    # a second batch keeps accumulating locally and is gathered again
+    total2, _ = o.render(cam, W, H, Dp, spp, 2, 9, total=total.copy(), rank=rank, world=world, threads=2, want_rgb8=False)
+    out2 = D.gather_accumulator(torch.from_numpy(total2.reshape(-1).copy()), dst=0)
+    if rank == 0:
+        full, _ = o.render(cam, W, H, Dp, 0, spp, 9, threads=2, want_rgb8=False)
+        full2, _ = o.render(cam, W, H, Dp, spp, 2, 9, total=full.copy(), threads=2, want_rgb8=False)
+        np.save(os.path.join(out_dir, "ok.npy"), np.array([
+            np.array_equal(out.numpy().reshape(H, W, 3), full),
+            np.array_equal(out2.numpy().reshape(H, W, 3), full2)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_split_and_gather(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ok = np.load(str(tmp_path / "ok.npy"))
+    assert ok.all()
+
+
+def test_tile_masks_partition_the_frame():
+    from pbrpathtracer_amd import distributed as D
+    for (w, h, world) in [(1280, 720, 8), (1920, 1080, 8), (70, 50, 3), (16, 16, 2), (5, 5, 4)]:
+        acc = np.zeros((h, w), np.int32)
+        for r in range(world):
+            m = D.tile_owner_mask(w, h, r, world)
+            acc += m
+            tiles = {(y // 16, x // 16) for y, x in zip(*np.nonzero(m))}
+            assert len(tiles) == D.owned_tile_count(w, h, r, world)
+        assert (acc == 1).all()
+    # load balance of the benchmark frame: every rank owns the same number of tiles +- 1
+    counts = [D.owned_tile_count(1280, 720, r, 8) for r in range(8)]
+    assert max(counts) - min(counts) <= 1
