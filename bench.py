@@ -60,7 +60,7 @@ def cpu_baseline(scene, name: str, budget_s: float = 12.0):
     w, h = scene.width, scene.height
     if ref_binding.available():
         ref = ref_binding.Ref()
-        ref.load_scene(scene)
+        ref.load_scene(scene, exact_pinhole=True)
         ref.lib.ref_seed(12345)
         import ctypes
         omp = ctypes.CDLL("libgomp.so.1")
@@ -83,6 +83,8 @@ def cpu_baseline(scene, name: str, budget_s: float = 12.0):
     pt.LoadSceneFile(pts)
     arrays = pt.StagedScene()
     cam = camera_from_scene(scene)
+    if scene.pinhole:
+        cam["aperture"] = 0.0
     o = OB.Oracle(arrays)
     ocam = OB.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
     cores = os.cpu_count() or 1
@@ -139,6 +141,8 @@ def main():
     t0 = time.time()
     pt.LoadSceneFile(pts)                       # LoadObject/SetMaterial/.../BuildBVH/SetCamera/SetResolution
     t_load = time.time() - t0
+    if scene.pinhole:
+        pt.SetCameraAperture(0.0)               # exact pinhole through the API; the .pts carries F = 1e9
     pt.SetSeed(args.seed)
     pt.SetTile(rank, world)
     W, H = pt.GetResolution()

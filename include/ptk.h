@@ -107,7 +107,9 @@ int ptk_set_camera(ptk_ctx* ctx, const float pos[3], const float dir[3], const f
  * accumulator (mTotalImg) and the RGB8 image on the device */
 int ptk_set_frame(ptk_ctx* ctx, int width, int height, int max_depth);
 
-/* multi-GPU: this context renders only the 16x16 pixel tiles t with t % world == rank */
+/* multi-GPU: this context renders only the 16x16 pixel tiles it owns: tile (tx, ty) belongs to rank
+ * (ty*tiles_x + (tx + 3*ty) % tiles_x) % world (round-robin, each tile row rotated by 3 so that a
+ * rank's tiles form diagonals and every rank gets an equal share of every image region) */
 int ptk_set_tile(ptk_ctx* ctx, int rank, int world);
 
 /* ResetImage (pathtracer.cpp:276-279, :745-751): zero the accumulator and the sample count */
@@ -143,8 +145,11 @@ int ptk_set_stream(ptk_ctx* ctx, void* hip_stream);
  * (ncclComm_t passed as void*); tiles a rank does not own are zero, so the sum is a gather */
 int ptk_gather_accum(ptk_ctx* ctx, void* rccl_comm, int root);
 
-/* tuning: "chunk" = samples per work item (default 32), "pass_bytes" = HBM budget of the sample
- * buffer between the trace and accumulate kernels (default 4 GiB).  Neither changes any result. */
+/* tuning (none changes any result): "chunk" = samples per work item (default 16); "pass_bytes" = HBM
+ * budget of the sample buffer between the trace and accumulate kernels (default 4 GiB);
+ * "shade_threshold" / "gen_threshold" = 64ths of a wave's live lanes that must queue before the
+ * shading / camera-ray block runs (default 48); "primary_cache" = 0/1, reuse the camera ray's closest
+ * hit across samples when the camera is a pinhole and the scene has no opacity texture (default 1). */
 int ptk_set_option(ptk_ctx* ctx, const char* name, double value);
 
 /* measurement: HIP-event times (on the context's stream) of the last ptk_render's kernels */

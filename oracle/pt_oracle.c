@@ -711,7 +711,8 @@ void orc_render(const orc_scene* s, const orc_camera* cam, int W, int H, int D,
         primary_row(&f, W, i, dirs);
         for (int j = 0; j < W; j++)                                            /* :783 */
         {
-            int tile = (i / ORC_TILE) * tiles_x + (j / ORC_TILE);
+            int ty = i / ORC_TILE, tx = j / ORC_TILE;
+            int tile = ty * tiles_x + (tx + 3 * ty) % tiles_x;      /* rows rotated by 3 tiles: diagonal ownership */
             if (tile % world != rank) continue;
             uint32_t pkey = pixel_key(seed, (uint32_t)(i * W + j));
             size_t px = ((size_t)(H - 1 - i) * W + j) * 3;                     /* :796 bottom-up */

@@ -85,8 +85,8 @@ void orc_destroy(orc_scene* s);
  * total: float RGB W*H*3, bottom-up rows (the reference's mTotalImg layout, pathtracer.cpp:796);
  * it is READ and accumulated into, sample by sample, like successive RenderFrame() calls.
  * rgb8 (may be NULL): clamp(total/(first_sample+spp))*255 truncated (pathtracer.cpp:802-812).
- * rank/world: only pixels of tiles owned by `rank` are rendered (tile = 16x16 pixels, owner =
- * tile_index % world).  threads<=0: OpenMP default. */
+ * rank/world: only pixels of tiles owned by `rank` are rendered (tile = 16x16 pixels, owner of tile
+ * (tx, ty) = (ty*tiles_x + (tx + 3*ty) % tiles_x) % world, as include/ptk.h ptk_set_tile).  threads<=0: OpenMP default. */
 void orc_render(const orc_scene* s, const orc_camera* cam, int width, int height, int max_depth,
                 uint32_t first_sample, uint32_t spp, uint64_t seed, int rank, int world,
                 float* total, uint8_t* rgb8, int threads);

@@ -35,7 +35,7 @@ class Ref:
         L.ref_seed.argtypes = [C.c_uint]
 
     # --- scene -------------------------------------------------------------------------------
-    def load_scene(self, scene, model_of=None):
+    def load_scene(self, scene, model_of=None, exact_pinhole=False):
         """scene: pbrpathtracer_amd.scenes.SceneDesc.  Follows Previewer::SendObjectsToPathTracer
         (previewer.cpp:770-817) + SetPathTracerCamera (:924-930) through the reference's API."""
         from pbrpathtracer_amd import scenes as S
@@ -60,6 +60,8 @@ class Ref:
         L.ref_set_projection(S.PTS_FOCAL, S.PTS_FOVY)
         L.ref_set_focal_dist(scene.focal_dist)
         L.ref_set_aperture(np.float32(S.PTS_FOCAL) / np.float32(scene.camera_f))
+        if exact_pinhole and getattr(scene, "pinhole", False):
+            L.ref_set_aperture(0.0)                       # SetCameraAperture(0), SURVEY.md §8(d2)
         L.ref_set_depth(scene.trace_depth)
         L.ref_set_resolution(scene.width, scene.height)
 

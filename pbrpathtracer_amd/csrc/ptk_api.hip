@@ -43,6 +43,9 @@ struct ptk_ctx {
     // frame
     int width = 0, height = 0, max_depth = 3;                                 // pathtracer.cpp:15
     float4* d_primary = nullptr;
+    float4* d_primary_hit = nullptr;  // primary-visibility cache (pinhole, no opacity textures)
+    bool primary_hit_dirty = true, scene_has_opacity = false;
+    int opt_primary_cache = 1;
     float* d_accum = nullptr;        // owned accumulator
     float* d_accum_bound = nullptr;  // caller-owned accumulator (ptk_bind_accum) or null
     uint8_t* d_rgb8 = nullptr;
@@ -129,7 +132,13 @@ int ensure_primary(ptk_ctx* c)
     launch_primary(pp, c->stream);
     HIPCHK(c, hipGetLastError());
     c->primary_dirty = false;
+    c->primary_hit_dirty = true;
     return PTK_OK;
+}
+
+bool primary_cacheable(const ptk_ctx* c)
+{
+    return c->opt_primary_cache && c->aperture == 0.0f && !c->scene_has_opacity && c->have_scene && c->d_primary_hit;
 }
 
 void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint64_t seed)
@@ -137,6 +146,7 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     std::memset(&p, 0, sizeof(p));
     p.nodes = c->d_nodes; p.tris = c->d_tris; p.shade = c->d_shade; p.mats = c->d_mats; p.lights = c->d_lights;
     p.texinfo = c->d_texinfo; p.texels = c->d_texels; p.primary = c->d_primary;
+    p.primary_hit = nullptr;
     p.samples = c->d_samples;
     p.shade_thr = c->opt_shade_thr; p.gen_thr = c->opt_gen_thr;
     p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.stats = c->d_stats;
@@ -168,6 +178,16 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
     RenderParams p;
     fill_params(c, p, first, spp, seed);
     p.accum = accum; p.rgb8 = rgb8; p.exit_flag = exit_flag;
+    if (primary_cacheable(c))
+    {
+        if (c->primary_hit_dirty)
+        {
+            launch_primary_hits(p, c->d_primary_hit, c->stream);
+            HIPCHK(c, hipGetLastError());
+            c->primary_hit_dirty = false;
+        }
+        p.primary_hit = c->d_primary_hit;
+    }
     const int tiles = owned_tiles(p);
     c->last_passes = 0; c->last_launches = 0;
     if (tiles == 0) return PTK_OK;
@@ -246,7 +266,7 @@ void ptk_destroy(ptk_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_mats); dfree(c->d_lights);
-    dfree(c->d_texinfo); dfree(c->d_texels); dfree(c->d_primary); dfree(c->d_accum); dfree(c->d_rgb8);
+    dfree(c->d_texinfo); dfree(c->d_texels); dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_accum); dfree(c->d_rgb8);
     dfree(c->d_exit); dfree(c->d_stats); dfree(c->d_samples);
     for (int i = 0; i < ptk_ctx::kMaxTimedPasses; i++)
         for (int k = 0; k < 3; k++)
@@ -414,6 +434,10 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     HIPCHK(c, up((void**)&c->d_texinfo, texinfo.data(), texinfo.size() * sizeof(int4)));
     HIPCHK(c, up((void**)&c->d_texels, texels.data(), texels.size() * 4));
     c->num_nodes = bvh.num_nodes; c->num_tris = n; c->num_lights = s->num_lights; c->bvh_depth = bvh.depth;
+    c->scene_has_opacity = false;
+    for (int32_t i = 0; i < n; i++)
+        if (s->materials[s->material[i]].tex[5] >= 0) { c->scene_has_opacity = true; break; }
+    c->primary_hit_dirty = true;
     c->have_scene = true;
     return PTK_OK;
 }
@@ -445,9 +469,10 @@ int ptk_set_frame(ptk_ctx* c, int width, int height, int max_depth)
     if (width != c->width || height != c->height || !c->d_accum)
     {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        dfree(c->d_primary); dfree(c->d_accum); dfree(c->d_rgb8);
+        dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_accum); dfree(c->d_rgb8);
         size_t px = (size_t)width * height;
         HIPCHK(c, hipMalloc(&c->d_primary, px * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_primary_hit, px * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->d_accum, px * 3 * sizeof(float)));
         HIPCHK(c, hipMalloc(&c->d_rgb8, px * 3));
         c->width = width; c->height = height;
@@ -667,6 +692,11 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     {
         if (!(value >= 1 && value <= 64)) return fail(c, PTK_ERR_BAD_ARG, "threshold must be in [1, 64] (64ths of a wave)");
         (name[0] == 's' ? c->opt_shade_thr : c->opt_gen_thr) = (int)value;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "primary_cache"))
+    {
+        c->opt_primary_cache = value != 0.0;
         return PTK_OK;
     }
     if (!std::strcmp(name, "pass_bytes"))

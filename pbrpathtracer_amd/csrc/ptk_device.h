@@ -57,6 +57,7 @@ struct RenderParams {
     const int4* texinfo;        // (width, height, first texel index, 0)
     const uint32_t* texels;     // RGBA8 atlas as packed words (r = low byte)
     const float4* primary;      // [H][W] unit primary directions before DOF (top-down rows)
+    const float4* primary_hit;  // [H][W] (bits tri | PTK_NOHIT, t, u, v) of the camera ray, or null when not cacheable
     float* accum;               // [H][W][3] float RGB, rows bottom-up (mTotalImg)
     uint8_t* rgb8;              // [H][W][3] RGB8, rows bottom-up (mOutImg)
     const uint32_t* exit_flag;
@@ -96,6 +97,7 @@ struct ProbeParams {
 void launch_trace(const RenderParams& p, int num_items, hipStream_t stream, bool stats);
 void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t stream);
 void launch_primary(const PrimaryParams& p, hipStream_t stream);
+void launch_primary_hits(const RenderParams& p, float4* out, hipStream_t stream);
 void launch_probe(const ProbeParams& p, hipStream_t stream);
 
 }  // namespace ptk

@@ -44,6 +44,9 @@ namespace ptk {
 #ifndef PTK_TRACE_BLOCK
 #define PTK_TRACE_BLOCK 64          // trace_kernel: one wave per workgroup -> finest-grained dispatch
 #endif
+#ifndef PTK_TRACE_WAVES
+#define PTK_TRACE_WAVES 4           // waves per SIMD the register allocator must allow (LDS stack: 8 KiB/wave -> 5)
+#endif
 #define PTK_NOHIT 0x7fffffff
 
 struct v3 { float x, y, z; };
@@ -292,7 +295,7 @@ __device__ __forceinline__ uint32_t pixel_key(uint32_t seed_lo, uint32_t seed_hi
 enum : int { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_DONE = 3 };
 
 template <bool STATS>
-__global__ __launch_bounds__(PTK_TRACE_BLOCK) void trace_kernel(const RenderParams P)
+__global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel(const RenderParams P)
 {
     __shared__ int lds_stack[PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
     if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
@@ -306,7 +309,8 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK) void trace_kernel(const RenderPara
     const int owned = subtile >> 2, quad = subtile & 3;
     const int tile = owned * P.world + P.rank;
     if (tile >= P.num_tiles || item >= P.num_items) return;
-    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    // rows are rotated by 3 tiles each so that a rank's tiles form diagonals, not columns (load balance)
+    const int ty = tile / P.tiles_x, tx = (tile % P.tiles_x + P.tiles_x - (3 * ty) % P.tiles_x) % P.tiles_x;
     const int px = tx * PTK_TILE + (quad & 1) * 8 + (lane & 7);
     const int py = ty * PTK_TILE + (quad >> 1) * 8 + (lane >> 3);     // row from the top (pathtracer.cpp:777)
     const bool valid = px < P.width && py < P.height;
@@ -342,6 +346,15 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK) void trace_kernel(const RenderPara
     uint32_t ray = 0;
     uint32_t sample = 0;            // index inside this chunk
     int st = (valid && s_count > 0) ? ST_GEN : ST_DONE;
+    Hit cached; cached.tri = PTK_NOHIT; cached.t = 0.0f; cached.u = 0.0f; cached.v = 0.0f;
+    if (P.primary_hit && valid)
+    {
+        float4 c = P.primary_hit[(size_t)py * P.width + px];
+        cached.tri = __float_as_int(c.x); cached.t = c.y; cached.u = c.z; cached.v = c.w;
+        // a pixel whose primary ray misses is black for every sample (pathtracer.cpp:550): nothing is
+        // traced or stored, and accumulate_kernel skips its (all-zero) samples
+        if (cached.tri == PTK_NOHIT) st = ST_DONE;
+    }
 
     // a finished path: its radiance goes to the sample buffer, the lane moves to its next sample
 #define PTK_FINISH_PATH()                                                                         \
@@ -620,6 +633,15 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK) void trace_kernel(const RenderPara
                 W.occl_tri = -1;
                 W.begin(ro, rd, P.num_nodes);
                 st = ST_TRAV;
+                if (P.primary_hit)
+                {
+                    // pinhole camera, no stochastic opacity: every sample of this pixel shoots the same
+                    // primary ray, so its closest hit was computed once by primary_hits_kernel
+                    W.best = cached;
+                    W.node = NODE_EXIT;
+                    ray = 1;
+                    st = ST_SHADE;              // (pixels whose primary ray misses never get here)
+                }
             }
         }
     }
@@ -656,14 +678,16 @@ __global__ __launch_bounds__(PTK_BLOCK) void accumulate_kernel(const RenderParam
     const int owned = blockIdx.x;
     const int tile = owned * P.world + P.rank;
     if (tile >= P.num_tiles) return;
-    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    // rows are rotated by 3 tiles each so that a rank's tiles form diagonals, not columns (load balance)
+    const int ty = tile / P.tiles_x, tx = (tile % P.tiles_x + P.tiles_x - (3 * ty) % P.tiles_x) % P.tiles_x;
     const int px = tx * PTK_TILE + (quad & 1) * 8 + (lane & 7);
     const int py = ty * PTK_TILE + (quad >> 1) * 8 + (lane >> 3);
     if (px >= P.width || py >= P.height) return;
     const size_t accidx = ((size_t)(P.height - 1 - py) * P.width + px) * 3;   // bottom-up (pathtracer.cpp:796)
     v3 acc = V(P.accum[accidx], P.accum[accidx + 1], P.accum[accidx + 2]);
     const size_t subtile = (size_t)owned * 4 + quad;
-    for (int c = 0; c < P.num_chunks; c++)
+    const bool black = P.primary_hit && __float_as_int(P.primary_hit[(size_t)py * P.width + px].x) == PTK_NOHIT;
+    for (int c = 0; c < (black ? 0 : P.num_chunks); c++)
     {
         const float4* in = P.samples + ((subtile * P.num_chunks + c) * P.chunk) * 64 + lane;
         const uint32_t s_begin = (uint32_t)c * (uint32_t)P.chunk;
@@ -707,6 +731,27 @@ __global__ void primary_dirs_kernel(const PrimaryParams P)
     }
 }
 
+// Primary-visibility cache for pinhole cameras (aperture == 0) in scenes without opacity textures: the
+// camera ray of a pixel is the same for every sample (pathtracer.cpp:785-791 with a zero lens offset),
+// so its closest hit is found once per camera / scene change instead of once per sample.
+__global__ __launch_bounds__(PTK_BLOCK) void primary_hits_kernel(const RenderParams P, float4* out)
+{
+    __shared__ int lds_stack[PTK_MAX_BVH_DEPTH * PTK_BLOCK];
+    const int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (i >= P.width * P.height) return;
+    Rng rng; rng.inc = 1u; rng.state = 0u; rng.key = 0u;            // no opacity draws can occur here
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    float4 d = P.primary[i];
+    const v3 camPos0 = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    v3 focalPoint = add(camPos0, muls(V(d.x, d.y, d.z), P.focal_dist));
+    v3 rd = normalize(sub(focalPoint, camPos0));
+    Walk W;
+    W.occl_tri = -1; W.occl_limit = 0.0f;
+    W.begin(camPos0, rd, P.num_nodes);
+    while (!W.done()) walk_step<false, PTK_BLOCK>(P, W, rng, 0u, lds_stack + threadIdx.x, cnt);
+    out[i] = make_float4(__int_as_float(W.best.tri), W.best.t, W.best.u, W.best.v);
+}
+
 // Parity probe: closest hit for a list of rays (no opacity draws differ: key 0, ray 0).
 __global__ __launch_bounds__(PTK_BLOCK) void probe_hits_kernel(const ProbeParams P)
 {
@@ -737,6 +782,11 @@ void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t strea
 {
     if (owned_tiles <= 0) return;
     hipLaunchKernelGGL(accumulate_kernel, dim3(owned_tiles), dim3(PTK_BLOCK), 0, stream, p);
+}
+void launch_primary_hits(const RenderParams& p, float4* out, hipStream_t stream)
+{
+    int n = p.width * p.height;
+    hipLaunchKernelGGL(primary_hits_kernel, dim3((n + PTK_BLOCK - 1) / PTK_BLOCK), dim3(PTK_BLOCK), 0, stream, p, out);
 }
 void launch_primary(const PrimaryParams& p, hipStream_t stream)
 {

@@ -1,5 +1,6 @@
 """Multi-GPU exchange step: one process per GPU (torchrun), the frame is tile-split across ranks
-(16x16 pixel tiles, tile t belongs to rank t % world — include/ptk.h `ptk_set_tile`) and the float
+(16x16 pixel tiles; tile (tx, ty) belongs to rank (ty*tiles_x + (tx + 3*ty) % tiles_x) % world, i.e.
+round-robin with every tile row rotated by 3 so a rank's tiles form diagonals — include/ptk.h `ptk_set_tile`) and the float
 accumulators are combined with ONE collective per batch of samples.
 
 The reference has no distributed path at all; this is the MI355X-native addition the
@@ -21,7 +22,7 @@ def tile_owner_mask(width: int, height: int, rank: int, world: int) -> np.ndarra
     """Boolean [H, W] mask (rows top-down) of the pixels rank `rank` renders."""
     tiles_x = (width + TILE - 1) // TILE
     ty, tx = np.meshgrid(np.arange(height) // TILE, np.arange(width) // TILE, indexing="ij")
-    return ((ty * tiles_x + tx) % world) == rank
+    return ((ty * tiles_x + (tx + 3 * ty) % tiles_x) % world) == rank
 
 
 def owned_tile_count(width: int, height: int, rank: int, world: int) -> int:

@@ -72,6 +72,9 @@ class SceneDesc:
     cam_rot: Tuple[float, float, float] = (0.0, 0.0, 0.0)  # degrees
     focal_dist: float = 3.5
     camera_f: float = 1.0e9  # f-number; aperture radius = 0.05 / F  (previewer.cpp:929)
+    # pinhole configs: the .pts carries a huge F (aperture 5e-11); drivers that want an exact pinhole call
+    # SetCameraAperture(0) after loading, as SURVEY.md §8(d2) prescribes for C1/C2
+    pinhole: bool = True
     objects: List[ObjectDesc] = field(default_factory=list)
 
 
@@ -313,7 +316,7 @@ def make_cornell(out_dir: str, width: int = 512, height: int = 512, depth: int =
 def make_spheres(out_dir: str, width: int = 1280, height: int = 720, depth: int = 8,
                  nu: int = 64, nv: int = 32, tex_size: int = 1024) -> SceneDesc:
     """C3: Cornell shell + 5x2 textured UV spheres (one translucent) + thin-lens DOF."""
-    sc = SceneDesc(trace_depth=depth, width=width, height=height, focal_dist=3.0, camera_f=1.0)
+    sc = SceneDesc(trace_depth=depth, width=width, height=height, focal_dist=3.0, camera_f=1.0, pinhole=False)
     sc.objects.append(_cornell_object(out_dir, uv=True))
     tex = {
         "albedo": (os.path.join(out_dir, "albedo.ppm"), tex_checker(tex_size)),

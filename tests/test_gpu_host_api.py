@@ -94,3 +94,32 @@ def test_full_size_properties(tmp_path):
     m = full.reshape(-1, 3).mean(0) / 16
     assert 0.03 < m.min() and m.max() < 0.2                  # the box covers ~22 % of the 16:9 frame
     pt.close()
+
+
+@pytest.mark.parametrize("cfg,kw,spp", [("C1", dict(width=96, height=80), 8), ("C4", dict(width=96, height=54, grid=20), 5)])
+def test_exact_pinhole_primary_cache(tmp_path, oracle_mod, cfg, kw, spp):
+    """SetCameraAperture(0): the camera ray of a pixel is the same for every sample, so the kernel reuses
+    its closest hit (primary-visibility cache) and skips pixels whose camera ray misses.  Must equal the
+    oracle (which traces every camera ray) and the cache-disabled kernel bit for bit."""
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
+    pts, scene, _ = S.build_config(cfg, str(tmp_path), **kw)
+    pt = PathTracer(0)
+    pt.LoadSceneFile(pts)
+    pt.SetCameraAperture(0.0)
+    pt.SetSeed(21)
+    W, H = pt.GetResolution(); D = pt.GetTraceDepth()
+    pt.RenderFrames(spp)
+    cached = pt.ReadAccumulation()
+    st = pt.context().collect_stats(0, spp, 21)
+    assert st["rays"] < st["samples"] + st["shadow_rays"] + st["hits_shaded"]     # camera rays were not traversed
+    ctx = pt.context(); ctx.set_option("primary_cache", 0)
+    pt.ResetImage(); pt.RenderFrames(spp)
+    plain = pt.ReadAccumulation()
+    assert np.array_equal(cached, plain)
+    o = oracle_mod.Oracle(pt.StagedScene())
+    cam = camera_from_scene(scene); cam["aperture"] = 0.0
+    ocam = oracle_mod.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+    ref, _ = o.render(ocam, W, H, D, 0, spp, 21)
+    assert np.array_equal(cached, ref)
+    pt.close()

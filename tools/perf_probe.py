@@ -12,7 +12,8 @@ arr = {k[6:]: z[k] for k in z.files if k.startswith("scene_")}
 c = ptk.Context(0)
 c.upload_scene(arr)
 cam = z["cam"]; proj = z["proj"]
-c.set_camera(cam[0:3], cam[3:6], cam[6:9], float(proj[0]), float(proj[1]), float(z["focal_dist"]), float(z["aperture"]))
+ap = float(os.environ.get("PTK_APERTURE", float(z["aperture"])))
+c.set_camera(cam[0:3], cam[3:6], cam[6:9], float(proj[0]), float(proj[1]), float(z["focal_dist"]), ap)
 c.set_frame(W, H, D)
 for kv in os.environ.get('PTK_OPTS','').split(','):
     if '=' in kv:
