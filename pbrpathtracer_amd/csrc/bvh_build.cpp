@@ -181,7 +181,13 @@ bool build_bvh(const float* verts, int32_t n, int max_depth, int leaf_max, Built
 {
     out = BuiltBvh();
     if (n <= 0) return true;
-    if (const char* e = std::getenv("PTK_LEAF_MAX")) leaf_max = std::atoi(e);
+    kTravCost = 1.0f;
+    // A handful of triangles (a bare Cornell box) gains nothing from a hierarchy: the surface-area
+    // heuristic overrates splits whose children still span the whole room, and every extra level costs
+    // a dependent 64-byte fetch.  Measured on MI355X (tools/perf_probe.py): two 6-triangle leaves under
+    // one node beat the 5-node tree by 16 % on the 12-triangle box; larger scenes prefer <= 4 per leaf.
+    if (n <= 16) { leaf_max = 8; kTravCost = 2.0f; }
+    if (const char* e = std::getenv("PTK_LEAF_MAX")) leaf_max = std::atoi(e);          // experiments only
     if (const char* e = std::getenv("PTK_TRAV_COST")) kTravCost = (float)std::atof(e);
     if (leaf_max < 1) leaf_max = 1;
     if (leaf_max > 8) leaf_max = 8;

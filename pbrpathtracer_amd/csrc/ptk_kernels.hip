@@ -167,6 +167,7 @@ struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex, walk_iters, w
 struct Walk {
     v3 ro, rd, inv;
     int node, sp;
+    int tri_next, tri_left;      // pending leaf: records [tri_next, tri_next + tri_left) still to test
     Hit best;
     // occl_tri >= 0 marks a shadow ray towards light triangle occl_tri whose sample lies at distance
     // ~occl_limit/(1-1e-4): any accepted hit on another triangle nearer than occl_limit decides the
@@ -174,6 +175,18 @@ struct Walk {
     int occl_tri;
     float occl_limit;
 
+    // node: >= 0 interior node to test next; NODE_EXIT finished; any other negative value = a leaf whose
+    // triangles are pending in (tri_next, tri_left)
+    __device__ __forceinline__ void set_node(int n)
+    {
+        node = n;
+        if (n < 0 && n != NODE_EXIT)
+        {
+            int code = ~n;
+            tri_next = code >> 3;
+            tri_left = (code & 7) + 1;
+        }
+    }
     __device__ __forceinline__ void begin(v3 o, v3 d, int num_nodes)
     {
         ro = o; rd = d;
@@ -181,6 +194,7 @@ struct Walk {
         inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
         node = num_nodes > 0 ? 0 : NODE_EXIT;
         sp = 0;
+        tri_next = 0; tri_left = 0;
         best.tri = PTK_NOHIT; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
     }
     __device__ __forceinline__ bool done() const { return node == NODE_EXIT; }
@@ -188,15 +202,68 @@ struct Walk {
     __device__ __forceinline__ void pop(const int* stack)
     {
         if (sp == 0) node = NODE_EXIT;
-        else { sp--; node = stack[sp * STRIDE]; }
+        else { sp--; set_node(stack[sp * STRIDE]); }
     }
 };
 
-// one BVH step: an interior node (two slab tests) or a leaf (its triangles)
+// One unit of BVH work per call: EITHER one interior node (two slab tests) OR one triangle of the
+// pending leaf.  Lanes of a wave therefore never wait for another lane's 4-triangle leaf: every
+// traversing lane does one unit per wave iteration, whichever kind it needs.
 template <bool STATS, int STRIDE, class PT>
 __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, uint32_t ray, int* stack, Counters& cnt)
 {
-    if (W.node >= 0)
+    if (W.tri_left > 0)
+    {
+        const v3 ro = W.ro, rd = W.rd;
+        const float4* tp = P.tris + (size_t)W.tri_next * TRI_F4;
+        float4 t0 = ldg4(tp), t1 = ldg4(tp + 1), t2 = ldg4(tp + 2);
+        W.tri_next++; W.tri_left--;
+        if (STATS) cnt.tris++;
+        bool accepted = false;
+        int tri = 0; float t = 0.0f, u = 0.0f, v = 0.0f;
+        do
+        {
+            // Moeller-Trumbore, PathTracer::IntersectTriangle pathtracer.cpp:373-409
+            v3 v0 = V(t0.x, t0.y, t0.z);
+            v3 edge1 = V(t0.w, t1.x, t1.y);
+            v3 edge2 = V(t1.z, t1.w, t2.x);
+            v3 h = cross(rd, edge2);
+            float a = dot(edge1, h);
+            if (fabsf(a) < PTK_EPS) break;
+            float f = 1.0f / a;
+            v3 s = sub(ro, v0);
+            u = f * dot(s, h);
+            if (u < 0.0f || u > 1.0f) break;
+            v3 q = cross(s, edge1);
+            v = f * dot(rd, q);
+            if (v < 0.0f || u + v > 1.0f) break;
+            t = f * dot(edge2, q);
+            if (!(t > PTK_EPS)) break;
+            tri = __float_as_int(t2.y);
+            if (!(t < W.best.t || (t == W.best.t && tri < W.best.tri))) break;
+            int otex = __float_as_int(t2.z);
+            if (otex >= 0)
+            {
+                // stochastic opacity, pathtracer.cpp:469-476 (GetUV :533-536)
+                const float4* sp4 = P.shade + (size_t)tri * SHADE_F4;
+                float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
+                float w = 1.0f - u - v;
+                float ux = w * s1.x + u * s1.z + v * s2.x;
+                float uy = w * s1.y + u * s1.w + v * s2.y;
+                float op = tex2d_r(P, otex, ux, uy);
+                if (STATS) cnt.tex++;
+                if (!(rng.opacity(ray, (uint32_t)tri) < op)) break;
+            }
+            accepted = true;
+        } while (false);
+        if (accepted)
+        {
+            W.best.tri = tri; W.best.t = t; W.best.u = u; W.best.v = v;
+            if (W.occl_tri >= 0 && tri != W.occl_tri && t < W.occl_limit) { W.sp = 0; W.tri_left = 0; }
+        }
+        if (W.tri_left == 0) W.template pop<STRIDE>(stack);
+    }
+    else if (W.node >= 0)
     {
         const float4* np = P.nodes + (size_t)W.node * NODE_F4;
         float4 q0 = ldg4(np), q1 = ldg4(np + 1), q2 = ldg4(np + 2), q3 = ldg4(np + 3);
@@ -218,57 +285,11 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
             bool lfirst = tnl <= tnr;
             stack[W.sp * STRIDE] = lfirst ? right : left;
             W.sp++;
-            W.node = lfirst ? left : right;
+            W.set_node(lfirst ? left : right);
         }
-        else if (hl) W.node = left;
-        else if (hr) W.node = right;
+        else if (hl) W.set_node(left);
+        else if (hr) W.set_node(right);
         else W.template pop<STRIDE>(stack);
-    }
-    else
-    {
-        int code = ~W.node;
-        int first = code >> 3, count = (code & 7) + 1;
-        const v3 ro = W.ro, rd = W.rd;
-        for (int k = 0; k < count; k++)
-        {
-            const float4* tp = P.tris + (size_t)(first + k) * TRI_F4;
-            float4 t0 = ldg4(tp), t1 = ldg4(tp + 1), t2 = ldg4(tp + 2);
-            if (STATS) cnt.tris++;
-            // Moeller-Trumbore, PathTracer::IntersectTriangle pathtracer.cpp:373-409
-            v3 v0 = V(t0.x, t0.y, t0.z);
-            v3 edge1 = V(t0.w, t1.x, t1.y);
-            v3 edge2 = V(t1.z, t1.w, t2.x);
-            v3 h = cross(rd, edge2);
-            float a = dot(edge1, h);
-            if (fabsf(a) < PTK_EPS) continue;
-            float f = 1.0f / a;
-            v3 s = sub(ro, v0);
-            float u = f * dot(s, h);
-            if (u < 0.0f || u > 1.0f) continue;
-            v3 q = cross(s, edge1);
-            float v = f * dot(rd, q);
-            if (v < 0.0f || u + v > 1.0f) continue;
-            float t = f * dot(edge2, q);
-            if (!(t > PTK_EPS)) continue;
-            int tri = __float_as_int(t2.y);
-            if (!(t < W.best.t || (t == W.best.t && tri < W.best.tri))) continue;
-            int otex = __float_as_int(t2.z);
-            if (otex >= 0)
-            {
-                // stochastic opacity, pathtracer.cpp:469-476 (GetUV :533-536)
-                const float4* sp4 = P.shade + (size_t)tri * SHADE_F4;
-                float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
-                float w = 1.0f - u - v;
-                float ux = w * s1.x + u * s1.z + v * s2.x;
-                float uy = w * s1.y + u * s1.w + v * s2.y;
-                float op = tex2d_r(P, otex, ux, uy);
-                if (STATS) cnt.tex++;
-                if (!(rng.opacity(ray, (uint32_t)tri) < op)) continue;
-            }
-            W.best.tri = tri; W.best.t = t; W.best.u = u; W.best.v = v;
-            if (W.occl_tri >= 0 && tri != W.occl_tri && t < W.occl_limit) { W.sp = 0; break; }
-        }
-        W.template pop<STRIDE>(stack);
     }
 }
 
