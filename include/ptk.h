@@ -147,8 +147,9 @@ int ptk_gather_accum(ptk_ctx* ctx, void* rccl_comm, int root);
 
 /* tuning (none changes any result): "chunk" = samples per work item (default 16); "pass_bytes" = HBM
  * budget of the sample buffer between the trace and accumulate kernels (default 4 GiB);
- * "shade_threshold" / "gen_threshold" = 64ths of a wave's live lanes that must queue before the
- * shading / camera-ray block runs (default 48); "primary_cache" = 0/1, reuse the camera ray's closest
+ * "shade_threshold" / "gen_threshold" = scheduling lambdas of the wave state machine in eighths
+ * (cost of the shading / camera-ray block relative to one BVH walk step; defaults: shading 200 for
+ * trees of depth <= 8 else 40 (0 = this automatic choice), camera rays 16); "primary_cache" = 0/1, reuse the camera ray's closest
  * hit across samples when the camera is a pinhole and the scene has no opacity texture (default 1). */
 int ptk_set_option(ptk_ctx* ctx, const char* name, double value);
 

@@ -60,7 +60,7 @@ struct ptk_ctx {
     float4* d_samples = nullptr;
     size_t samples_bytes = 0;
     int opt_chunk = 16;                          // samples per work item
-    int opt_shade_thr = 48, opt_gen_thr = 48;    // see trace_kernel (1/64ths of the live lanes)
+    int opt_shade_thr = 0, opt_gen_thr = 16;     // scheduling lambdas in eighths, see trace_kernel; 0 = by tree depth
     size_t opt_pass_bytes = (size_t)4 << 30;     // sample-buffer budget per pass
 
     static constexpr int kMaxTimedPasses = 64;
@@ -148,7 +148,10 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     p.texinfo = c->d_texinfo; p.texels = c->d_texels; p.primary = c->d_primary;
     p.primary_hit = nullptr;
     p.samples = c->d_samples;
-    p.shade_thr = c->opt_shade_thr; p.gen_thr = c->opt_gen_thr;
+    // shallow trees give short, uniform walks: waiting for stragglers is cheap and re-synchronises the
+    // wave (lambda 25); deep trees have heavy-tailed walks: shade small batches early (lambda 5)
+    p.shade_thr = c->opt_shade_thr > 0 ? c->opt_shade_thr : (c->bvh_depth <= 8 ? 200 : 40);
+    p.gen_thr = c->opt_gen_thr;
     p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.stats = c->d_stats;
     p.num_nodes = c->num_nodes; p.num_lights = c->num_lights;
     p.width = c->width; p.height = c->height; p.max_depth = c->max_depth;
@@ -690,7 +693,7 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     }
     if (!std::strcmp(name, "shade_threshold") || !std::strcmp(name, "gen_threshold"))
     {
-        if (!(value >= 1 && value <= 64)) return fail(c, PTK_ERR_BAD_ARG, "threshold must be in [1, 64] (64ths of a wave)");
+        if (!(value >= 0 && value <= 4096)) return fail(c, PTK_ERR_BAD_ARG, "threshold (lambda in eighths) must be in [0, 4096]");
         (name[0] == 's' ? c->opt_shade_thr : c->opt_gen_thr) = (int)value;
         return PTK_OK;
     }

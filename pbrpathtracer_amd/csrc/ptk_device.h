@@ -48,7 +48,7 @@ struct RenderParams {
     float4* samples;
     int chunk, num_chunks;      // samples per work item, work items per 8x8 tile
     int num_items;              // owned tiles * 4 * num_chunks
-    int shade_thr, gen_thr;     // state-machine thresholds in 1/64ths of a wave's live lanes
+    int shade_thr, gen_thr;     // scheduling lambdas (eighths): cost of the shade / gen block in walk steps
     const float4* nodes;
     const float4* tris;
     const float4* shade;

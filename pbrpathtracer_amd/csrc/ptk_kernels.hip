@@ -385,6 +385,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
         st = sample < s_count ? ST_GEN : ST_DONE;                                                 \
     } while (0)
 
+    int debt_shade = 0, debt_gen = 0;      // wave-uniform: lane-iterations wasted by parked lanes
     for (;;)
     {
         const unsigned long long m_trav = __ballot(st == ST_TRAV);
@@ -394,13 +395,18 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
         const int n_live = n_trav + n_shade + n_gen;
         if (n_live == 0) break;
 
-        // Block choice: shading is the expensive block, so it waits until shade_thr/64 of the
-        // live lanes have queued up (or nothing else can make progress); the walk otherwise keeps
-        // stepping, and camera-ray generation (cheap) runs when no lane is traversing.
-        const bool run_shade = n_shade * 64 >= n_live * P.shade_thr || (n_trav == 0 && n_gen == 0);
-        if (!run_shade && n_trav > 0 && (n_gen * 64 < n_live * P.gen_thr))
+        // Block choice ("ski rental"): a lane parked in SHADE / GEN wastes one lane-iteration for
+        // every walk iteration it sits out, while running its block now wastes the lanes that are not
+        // parked there.  The walk keeps stepping until the lane-iterations wasted by the parked lanes
+        // (debt, accumulated per walk iteration) exceed lambda x the lanes the block would leave idle,
+        // with lambda ~ cost(block) / cost(walk step) (P.shade_thr, P.gen_thr in eighths).  Short walks
+        // (a bare Cornell box) thus batch ~3/4 of a wave per shade call, deep trees with straggling
+        // rays shade small batches early instead of idling - measured optimum in both regimes.
+        bool run_shade = n_trav == 0 && n_shade >= n_gen && n_shade > 0;
+        bool run_gen = n_trav == 0 && !run_shade;
+        if (n_trav > 0)
         {
-            // ---- BVH walk: keep stepping while at least half of the live lanes are traversing ----
+            // ---- BVH walk ----
             do
             {
                 if (STATS) { const uint32_t nt = (uint32_t)__popcll(__ballot(st == ST_TRAV)); if (lane == 0) { cnt.walk_iters++; cnt.walk_lanes += nt; } }
@@ -427,13 +433,19 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
                 }
                 const int nt = __popcll(__ballot(st == ST_TRAV));
                 const int ns = __popcll(__ballot(st == ST_SHADE));
-                if (nt == 0 || ns * 64 >= n_live * P.shade_thr) break;
-                if ((n_live - nt - ns) * 64 >= n_live * P.gen_thr) break;
+                const int ng = __popcll(__ballot(st == ST_GEN));
+                const int nl = nt + ns + ng;
+                debt_shade += ns; debt_gen += ng;
+                if (ns > 0 && debt_shade * 8 >= P.shade_thr * (nl - ns)) { run_shade = true; break; }
+                if (ng > 0 && debt_gen * 8 >= P.gen_thr * (nl - ng)) { run_gen = true; break; }
+                if (nt == 0) break;
             } while (true);
+            if (!run_shade && !run_gen) continue;        // the walk ran dry: re-vote
         }
-        else if (run_shade)
+        if (run_shade) debt_shade = 0; else debt_gen = 0;
+        if (run_shade)
         {
-            if (STATS && lane == 0) { cnt.shade_execs++; cnt.shade_lanes += (uint32_t)n_shade; }
+            if (STATS) { const uint32_t nsx = (uint32_t)__popcll(__ballot(st == ST_SHADE)); if (lane == 0) { cnt.shade_execs++; cnt.shade_lanes += nsx; } }
             if (st == ST_SHADE)
             {
                 // ---- one surface interaction of PathTracer::Trace, pathtracer.cpp:551-727 ----
@@ -630,7 +642,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
         }
         else
         {
-            if (STATS && lane == 0) { cnt.gen_execs++; cnt.gen_lanes += (uint32_t)n_gen; }
+            if (STATS) { const uint32_t ngx = (uint32_t)__popcll(__ballot(st == ST_GEN)); if (lane == 0) { cnt.gen_execs++; cnt.gen_lanes += ngx; } }
             if (st == ST_GEN)
             {
                 // ---- camera ray with thin-lens DOF, pathtracer.cpp:785-791 + SampleCircle :734-739 ----
