@@ -337,16 +337,10 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     const bool valid = px < P.width && py < P.height;
     const uint32_t s_begin = (uint32_t)chunk_id * (uint32_t)P.chunk;
     const uint32_t s_count = min((uint32_t)P.chunk, P.spp - s_begin);  // host guarantees s_begin < spp
-    float4* out = P.samples + ((size_t)item * P.chunk) * 64 + lane;
+    const size_t out_base = ((size_t)item * P.chunk) * 64 + lane;      // sample s of this lane: P.samples[out_base + s * 64]
 
-    v3 dir0 = V(0.0f, 0.0f, 1.0f);
-    uint32_t pkey = 0;
-    if (valid)
-    {
-        float4 d = P.primary[(size_t)py * P.width + px];
-        dir0 = V(d.x, d.y, d.z);
-        pkey = pixel_key(P.seed_lo, P.seed_hi, (uint32_t)(py * P.width + px));
-    }
+    const uint32_t pix = valid ? (uint32_t)(py * P.width + px) : 0u;    // row-major from the top
+    const uint32_t pkey = valid ? pixel_key(P.seed_lo, P.seed_hi, pix) : 0u;
     const v3 camPos0 = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
     const v3 camRight = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
     const v3 camUp = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
@@ -358,7 +352,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
 
     // per-lane path state
     Walk W;
-    W.begin(camPos0, dir0, 0);
+    W.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0);
     W.occl_tri = -1; W.occl_limit = 0.0f;
     v3 L = V(0.0f, 0.0f, 0.0f), T = V(1.0f, 1.0f, 1.0f);
     v3 Tdi = V(0.0f, 0.0f, 0.0f), nextDir = V(0.0f, 0.0f, 1.0f);
@@ -367,20 +361,17 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     uint32_t ray = 0;
     uint32_t sample = 0;            // index inside this chunk
     int st = (valid && s_count > 0) ? ST_GEN : ST_DONE;
-    Hit cached; cached.tri = PTK_NOHIT; cached.t = 0.0f; cached.u = 0.0f; cached.v = 0.0f;
     if (P.primary_hit && valid)
     {
-        float4 c = P.primary_hit[(size_t)py * P.width + px];
-        cached.tri = __float_as_int(c.x); cached.t = c.y; cached.u = c.z; cached.v = c.w;
         // a pixel whose primary ray misses is black for every sample (pathtracer.cpp:550): nothing is
         // traced or stored, and accumulate_kernel skips its (all-zero) samples
-        if (cached.tri == PTK_NOHIT) st = ST_DONE;
+        if (__float_as_int(P.primary_hit[pix].x) == PTK_NOHIT) st = ST_DONE;
     }
 
     // a finished path: its radiance goes to the sample buffer, the lane moves to its next sample
 #define PTK_FINISH_PATH()                                                                         \
     do {                                                                                          \
-        out[(size_t)sample * 64] = make_float4(L.x, L.y, L.z, 0.0f);                               \
+        P.samples[out_base + (size_t)sample * 64] = make_float4(L.x, L.y, L.z, 0.0f);              \
         sample++;                                                                                 \
         st = sample < s_count ? ST_GEN : ST_DONE;                                                 \
     } while (0)
@@ -648,6 +639,9 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
                 // ---- camera ray with thin-lens DOF, pathtracer.cpp:785-791 + SampleCircle :734-739 ----
                 rng.state = hash32(P.first_sample + s_begin + sample + pkey);
                 rng.key = rng.state;
+                // per-pixel constants are re-read here (L1/L2 hits) instead of living in registers
+                const float4 d0 = P.primary[pix];
+                const v3 dir0 = V(d0.x, d0.y, d0.z);
                 v3 focalPoint = add(camPos0, muls(dir0, P.focal_dist));
                 float r1 = rng.next(), r2 = rng.next();          // always two draws, even with a pinhole
                 v3 ro = camPos0;
@@ -670,7 +664,8 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
                 {
                     // pinhole camera, no stochastic opacity: every sample of this pixel shoots the same
                     // primary ray, so its closest hit was computed once by primary_hits_kernel
-                    W.best = cached;
+                    const float4 c = P.primary_hit[pix];
+                    W.best.tri = __float_as_int(c.x); W.best.t = c.y; W.best.u = c.z; W.best.v = c.w;
                     W.node = NODE_EXIT;
                     ray = 1;
                     st = ST_SHADE;              // (pixels whose primary ray misses never get here)
