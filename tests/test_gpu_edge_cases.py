@@ -1,0 +1,129 @@
+"""Edge cases the reference's semantics imply (it has no tests of its own): empty / tiny / degenerate
+scenes, no lights, extreme trace depths, ragged and 1-pixel frames, missing textures — HIP path vs oracle,
+bit for bit, through the C-ABI."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, scene_from_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pbrpathtracer_amd import ptk
+    c = ptk.Context(0)
+    yield c
+    c.close()
+
+
+def _cam(z, aperture=None):
+    cam, proj = z["cam"], z["proj"]
+    return dict(pos=cam[0:3], dir=cam[3:6], up=cam[6:9], focal=float(proj[0]), fovy=float(proj[1]),
+                focal_dist=float(z["focal_dist"]), aperture=float(z["aperture"]) if aperture is None else aperture)
+
+
+def _both(ctx, OB, arrays, cam, W, H, D, spp, seed=5):
+    o = OB.Oracle(arrays)
+    ocam = OB.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+    ref, ref8 = o.render(ocam, W, H, D, 0, spp, seed)
+    ctx.upload_scene(arrays); ctx.set_camera(**cam); ctx.set_frame(W, H, D); ctx.set_tile(0, 1); ctx.reset()
+    ctx.render(0, spp, seed)
+    return ref, ref8, ctx.read_accum(), ctx.resolve_rgb8()
+
+
+def _empty_like(arrays, n=0):
+    a = {k: v[:n].copy() if k in ("verts", "normals", "uvs", "tbn", "smoothing", "material") else v.copy() for k, v in arrays.items()}
+    a["lights"] = np.zeros(0, np.int32)
+    return a
+
+
+def test_empty_scene_renders_black(ctx, oracle_mod):
+    z = load_golden("tier_s_cornell.npz")
+    arrays = _empty_like(scene_from_golden(z))
+    ref, ref8, got, got8 = _both(ctx, oracle_mod, arrays, _cam(z), 33, 17, 4, 3)
+    assert not got.any() and not got8.any() and np.array_equal(ref, got)
+    assert ctx.bvh_info()[0] == 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_few_triangles(ctx, oracle_mod, n):
+    z = load_golden("tier_s_cornell.npz")
+    full = scene_from_golden(z)
+    keep = [int(full["lights"][0])] + [i for i in range(len(full["verts"])) if i != int(full["lights"][0])][: n - 1]
+    a = {k: (v[keep].copy() if k in ("verts", "normals", "uvs", "tbn", "smoothing", "material") else v.copy()) for k, v in full.items()}
+    a["lights"] = np.array([0], np.int32)
+    ref, ref8, got, got8 = _both(ctx, oracle_mod, a, _cam(z), 40, 40, 4, 4)
+    assert np.array_equal(ref, got) and np.array_equal(ref8, got8)
+
+
+def test_no_lights_and_degenerate_triangles(ctx, oracle_mod):
+    z = load_golden("tier_s_glass.npz")
+    a = scene_from_golden(z)
+    a["lights"] = np.zeros(0, np.int32)                       # DirectIllumimation returns 0 (pathtracer.cpp:506-507)
+    a["materials"] = a["materials"].copy(); a["materials"]["emissive"][:] = 0
+    a["verts"] = a["verts"].copy()
+    a["verts"][3, 3:6] = a["verts"][3, 0:3]                   # zero-area triangle: |a| < EPS cull (pathtracer.cpp:387)
+    a["verts"][5, 6:9] = a["verts"][5, 3:6]
+    ref, ref8, got, got8 = _both(ctx, oracle_mod, a, _cam(z), 48, 32, 6, 3)
+    assert np.array_equal(ref, got) and not got.any()          # nothing emits -> black, but every branch ran
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2, 12])
+def test_trace_depth_extremes(ctx, oracle_mod, depth):
+    z = load_golden("tier_s_glass.npz")
+    ref, ref8, got, got8 = _both(ctx, oracle_mod, scene_from_golden(z), _cam(z), 40, 28, depth, 3)
+    assert np.array_equal(ref, got) and np.array_equal(ref8, got8)
+    if depth == 0:
+        assert not got.any()                                   # `iter < mMaxDepth` never holds (pathtracer.cpp:571)
+
+
+@pytest.mark.parametrize("wh", [(1, 1), (17, 1), (1, 19), (16, 16), (15, 33)])
+def test_ragged_frames(ctx, oracle_mod, wh):
+    z = load_golden("tier_s_opacity.npz")
+    W, H = wh
+    ref, ref8, got, got8 = _both(ctx, oracle_mod, scene_from_golden(z), _cam(z), W, H, 4, 5)
+    assert got.shape == (H, W, 3) and np.array_equal(ref, got) and np.array_equal(ref8, got8)
+
+
+def test_missing_texture_samples_as_zero(ctx, oracle_mod):
+    """An Image whose file failed to load has no data and samples as 0 (image.cpp:65-66): staged as a
+    zero-extent texture."""
+    z = load_golden("tier_s_opacity.npz")
+    a = scene_from_golden(z)
+    a["textures"] = a["textures"].copy()
+    a["textures"]["width"][0] = 0; a["textures"]["height"][0] = 0
+    ref, ref8, got, got8 = _both(ctx, oracle_mod, a, _cam(z), 40, 30, 4, 4)
+    assert np.array_equal(ref, got)
+
+
+def test_many_spp_chunks_and_passes(ctx, oracle_mod):
+    """spp not a multiple of the chunk, several passes through a tiny sample-buffer budget: identical."""
+    z = load_golden("tier_s_cornell.npz")
+    arrays = scene_from_golden(z); cam = _cam(z)
+    ref, ref8, got, got8 = _both(ctx, oracle_mod, arrays, cam, 48, 32, 4, 37)
+    assert np.array_equal(ref, got)
+    ctx.set_option("pass_bytes", 1 << 20); ctx.set_option("chunk", 5)
+    ctx.reset(); ctx.render(0, 37, 5)
+    again = ctx.read_accum()
+    ctx.set_option("pass_bytes", float(4 << 30)); ctx.set_option("chunk", 16)
+    assert np.array_equal(again, got)
+
+
+def test_bad_arguments_are_errors(ctx):
+    from pbrpathtracer_amd import ptk
+    z = load_golden("tier_s_cornell.npz")
+    a = scene_from_golden(z)
+    bad = dict(a); bad["material"] = a["material"].copy(); bad["material"][0] = 99
+    with pytest.raises(ptk.PtkError):
+        ctx.upload_scene(bad)
+    bad = dict(a); bad["lights"] = np.array([12345], np.int32)
+    with pytest.raises(ptk.PtkError):
+        ctx.upload_scene(bad)
+    with pytest.raises(ptk.PtkError):
+        ctx.set_frame(0, 10, 3)
+    with pytest.raises(ptk.PtkError):
+        ctx.set_tile(2, 2)
+    with pytest.raises(ptk.PtkError):
+        ctx.set_option("no_such_option", 1)
+    ctx.upload_scene(a)                                        # the context stays usable
