@@ -204,10 +204,11 @@ def main():
     out = None
     if rank == 0:
         # algorithmic bytes from the kernel's own traversal counts (untimed counters-enabled variant)
+        ntri_for_chunk = ctx.bvh_info()[2]
         ctx.set_tile(0, 1)
         stats = ctx.collect_stats(0, min(spp, 8), args.seed)
         ctx.set_tile(rank, world)
-        chunk = min(spp, 16)      # ptk default samples per work item
+        chunk = min(spp, 32 if ntri_for_chunk <= 16 else 16)      # ptk's automatic samples per work item
         bps = algorithmic_bytes_per_sample(stats, chunk)
         launch_samples = float(W) * H * spp / world
         avg_ms = float(np.mean(ev_ms))

@@ -145,7 +145,10 @@ int ptk_set_stream(ptk_ctx* ctx, void* hip_stream);
  * (ncclComm_t passed as void*); tiles a rank does not own are zero, so the sum is a gather */
 int ptk_gather_accum(ptk_ctx* ctx, void* rccl_comm, int root);
 
-/* tuning (none changes any result): "chunk" = samples per work item (default 16); "pass_bytes" = HBM
+/* tuning (none changes any result): "chunk" = samples per work item (default 0 = automatic: 16, or 32
+ * for scenes of <= 16 triangles); "flat" = 0/1, scenes of <= 16 triangles skip the BVH walk and test
+ * every triangle with scalar loads (default 1), "flat_shade_weight" / "flat_gen_weight" = its block-choice
+ * weights in eighths (defaults 8 / 64); "pass_bytes" = HBM
  * budget of the sample buffer between the trace and accumulate kernels (default 4 GiB);
  * "shade_threshold" / "gen_threshold" = scheduling lambdas of the wave state machine in eighths
  * (cost of the shading / camera-ray block relative to one BVH walk step; defaults: shading 200 for

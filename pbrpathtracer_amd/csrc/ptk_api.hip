@@ -46,6 +46,8 @@ struct ptk_ctx {
     float4* d_primary_hit = nullptr;  // primary-visibility cache (pinhole, no opacity textures)
     bool primary_hit_dirty = true, scene_has_opacity = false;
     int opt_primary_cache = 1;
+    int opt_flat_shade_w = 8, opt_flat_gen_w = 64;
+    int opt_flat = 1;                    // scenes of <= PTK_FLAT_MAX triangles: no BVH walk (trace_kernel<.., FLAT>)
     float* d_accum = nullptr;        // owned accumulator
     float* d_accum_bound = nullptr;  // caller-owned accumulator (ptk_bind_accum) or null
     uint8_t* d_rgb8 = nullptr;
@@ -59,7 +61,7 @@ struct ptk_ctx {
     // sample buffer between trace_kernel and accumulate_kernel (grown on demand, never shrunk)
     float4* d_samples = nullptr;
     size_t samples_bytes = 0;
-    int opt_chunk = 16;                          // samples per work item
+    int opt_chunk = 0;                           // samples per work item; 0 = automatic (16, or 32 in FLAT mode)
     int opt_shade_thr = 0, opt_gen_thr = 16;     // scheduling lambdas in eighths, see trace_kernel; 0 = by tree depth
     size_t opt_pass_bytes = (size_t)4 << 30;     // sample-buffer budget per pass
 
@@ -154,6 +156,8 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     p.gen_thr = c->opt_gen_thr;
     p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.stats = c->d_stats;
     p.num_nodes = c->num_nodes; p.num_lights = c->num_lights;
+    p.flat_count = (c->opt_flat && c->num_tris <= 16) ? c->num_tris : 0;
+    p.flat_shade_w = c->opt_flat_shade_w; p.flat_gen_w = c->opt_flat_gen_w;
     p.width = c->width; p.height = c->height; p.max_depth = c->max_depth;
     p.tiles_x = (c->width + PTK_TILE - 1) / PTK_TILE;
     p.num_tiles = p.tiles_x * ((c->height + PTK_TILE - 1) / PTK_TILE);
@@ -195,13 +199,15 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
     c->last_passes = 0; c->last_launches = 0;
     if (tiles == 0) return PTK_OK;
     const size_t per_sample = (size_t)tiles * 4 * 64 * sizeof(float4);
+    // longer chunks amortise the end-of-chunk tail; the FLAT walk is short and uniform so its tail is cheap
+    const int chunk_opt = c->opt_chunk > 0 ? c->opt_chunk : (p.flat_count > 0 ? 32 : 16);
     uint32_t max_pass = (uint32_t)std::max<size_t>(1, c->opt_pass_bytes / per_sample);
-    if (max_pass > (uint32_t)c->opt_chunk) max_pass -= max_pass % (uint32_t)c->opt_chunk;
+    if (max_pass > (uint32_t)chunk_opt) max_pass -= max_pass % (uint32_t)chunk_opt;
     uint32_t done = 0;
     while (done < spp)
     {
         const uint32_t n = std::min(spp - done, max_pass);
-        const int chunk = (int)std::min<uint32_t>(n, (uint32_t)c->opt_chunk);
+        const int chunk = (int)std::min<uint32_t>(n, (uint32_t)chunk_opt);
         const int num_chunks = (int)((n + chunk - 1) / chunk);
         const size_t need = per_sample * (size_t)chunk * num_chunks;
         if (need > c->samples_bytes)
@@ -687,7 +693,7 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     if (!c || !name) return PTK_ERR_BAD_ARG;
     if (!std::strcmp(name, "chunk"))
     {
-        if (!(value >= 1 && value <= 4096)) return fail(c, PTK_ERR_BAD_ARG, "chunk must be in [1, 4096]");
+        if (!(value >= 0 && value <= 4096)) return fail(c, PTK_ERR_BAD_ARG, "chunk must be in [0, 4096] (0 = automatic)");
         c->opt_chunk = (int)value;
         return PTK_OK;
     }
@@ -695,6 +701,17 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     {
         if (!(value >= 0 && value <= 4096)) return fail(c, PTK_ERR_BAD_ARG, "threshold (lambda in eighths) must be in [0, 4096]");
         (name[0] == 's' ? c->opt_shade_thr : c->opt_gen_thr) = (int)value;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "flat_shade_weight") || !std::strcmp(name, "flat_gen_weight"))
+    {
+        if (!(value >= 1 && value <= 4096)) return fail(c, PTK_ERR_BAD_ARG, "weight (eighths) must be in [1, 4096]");
+        (name[5] == 's' ? c->opt_flat_shade_w : c->opt_flat_gen_w) = (int)value;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "flat"))
+    {
+        c->opt_flat = value != 0.0;
         return PTK_OK;
     }
     if (!std::strcmp(name, "primary_cache"))

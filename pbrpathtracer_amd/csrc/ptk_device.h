@@ -63,6 +63,8 @@ struct RenderParams {
     const uint32_t* exit_flag;
     unsigned long long* stats;  // 7 counters (STATS variant only)
     int num_nodes, num_lights;
+    int flat_shade_w, flat_gen_w; // FLAT block-choice weights (eighths) of the shade / camera-ray blocks vs the triangle pass
+    int flat_count;             // > 0: tiny scene, test all flat_count triangle records per ray without a BVH walk
     int width, height, max_depth;
     int tiles_x, num_tiles;
     int rank, world;

@@ -206,6 +206,50 @@ struct Walk {
     }
 };
 
+// Candidate test of one triangle record: Hit's leaf branch (pathtracer.cpp:463-489) = Moeller-Trumbore
+// + order-independent closest rule + stochastic opacity.  Returns true when the walk can stop (an
+// occluder decided a shadow ray).
+template <bool STATS, class PT>
+__device__ __forceinline__ bool tri_test(const PT& P, Walk& W, float4 t0, float4 t1, float4 t2, const Rng& rng,
+                                         uint32_t ray, Counters& cnt)
+{
+    const v3 ro = W.ro, rd = W.rd;
+    if (STATS) cnt.tris++;
+    // Moeller-Trumbore, PathTracer::IntersectTriangle pathtracer.cpp:373-409
+    v3 v0 = V(t0.x, t0.y, t0.z);
+    v3 edge1 = V(t0.w, t1.x, t1.y);
+    v3 edge2 = V(t1.z, t1.w, t2.x);
+    v3 h = cross(rd, edge2);
+    float a = dot(edge1, h);
+    if (fabsf(a) < PTK_EPS) return false;
+    float f = 1.0f / a;
+    v3 s = sub(ro, v0);
+    float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    v3 q = cross(s, edge1);
+    float v = f * dot(rd, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = f * dot(edge2, q);
+    if (!(t > PTK_EPS)) return false;
+    int tri = __float_as_int(t2.y);
+    if (!(t < W.best.t || (t == W.best.t && tri < W.best.tri))) return false;
+    int otex = __float_as_int(t2.z);
+    if (otex >= 0)
+    {
+        // stochastic opacity, pathtracer.cpp:469-476 (GetUV :533-536)
+        const float4* sp4 = P.shade + (size_t)tri * SHADE_F4;
+        float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
+        float w = 1.0f - u - v;
+        float ux = w * s1.x + u * s1.z + v * s2.x;
+        float uy = w * s1.y + u * s1.w + v * s2.y;
+        float op = tex2d_r(P, otex, ux, uy);
+        if (STATS) cnt.tex++;
+        if (!(rng.opacity(ray, (uint32_t)tri) < op)) return false;
+    }
+    W.best.tri = tri; W.best.t = t; W.best.u = u; W.best.v = v;
+    return W.occl_tri >= 0 && tri != W.occl_tri && t < W.occl_limit;
+}
+
 // One unit of BVH work per call: EITHER one interior node (two slab tests) OR one triangle of the
 // pending leaf.  Lanes of a wave therefore never wait for another lane's 4-triangle leaf: every
 // traversing lane does one unit per wave iteration, whichever kind it needs.
@@ -214,53 +258,10 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
 {
     if (W.tri_left > 0)
     {
-        const v3 ro = W.ro, rd = W.rd;
         const float4* tp = P.tris + (size_t)W.tri_next * TRI_F4;
         float4 t0 = ldg4(tp), t1 = ldg4(tp + 1), t2 = ldg4(tp + 2);
         W.tri_next++; W.tri_left--;
-        if (STATS) cnt.tris++;
-        bool accepted = false;
-        int tri = 0; float t = 0.0f, u = 0.0f, v = 0.0f;
-        do
-        {
-            // Moeller-Trumbore, PathTracer::IntersectTriangle pathtracer.cpp:373-409
-            v3 v0 = V(t0.x, t0.y, t0.z);
-            v3 edge1 = V(t0.w, t1.x, t1.y);
-            v3 edge2 = V(t1.z, t1.w, t2.x);
-            v3 h = cross(rd, edge2);
-            float a = dot(edge1, h);
-            if (fabsf(a) < PTK_EPS) break;
-            float f = 1.0f / a;
-            v3 s = sub(ro, v0);
-            u = f * dot(s, h);
-            if (u < 0.0f || u > 1.0f) break;
-            v3 q = cross(s, edge1);
-            v = f * dot(rd, q);
-            if (v < 0.0f || u + v > 1.0f) break;
-            t = f * dot(edge2, q);
-            if (!(t > PTK_EPS)) break;
-            tri = __float_as_int(t2.y);
-            if (!(t < W.best.t || (t == W.best.t && tri < W.best.tri))) break;
-            int otex = __float_as_int(t2.z);
-            if (otex >= 0)
-            {
-                // stochastic opacity, pathtracer.cpp:469-476 (GetUV :533-536)
-                const float4* sp4 = P.shade + (size_t)tri * SHADE_F4;
-                float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
-                float w = 1.0f - u - v;
-                float ux = w * s1.x + u * s1.z + v * s2.x;
-                float uy = w * s1.y + u * s1.w + v * s2.y;
-                float op = tex2d_r(P, otex, ux, uy);
-                if (STATS) cnt.tex++;
-                if (!(rng.opacity(ray, (uint32_t)tri) < op)) break;
-            }
-            accepted = true;
-        } while (false);
-        if (accepted)
-        {
-            W.best.tri = tri; W.best.t = t; W.best.u = u; W.best.v = v;
-            if (W.occl_tri >= 0 && tri != W.occl_tri && t < W.occl_limit) { W.sp = 0; W.tri_left = 0; }
-        }
+        if (tri_test<STATS>(P, W, t0, t1, t2, rng, ray, cnt)) { W.sp = 0; W.tri_left = 0; }
         if (W.tri_left == 0) W.template pop<STRIDE>(stack);
     }
     else if (W.node >= 0)
@@ -315,10 +316,14 @@ __device__ __forceinline__ uint32_t pixel_key(uint32_t seed_lo, uint32_t seed_hi
 
 enum : int { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_DONE = 3 };
 
-template <bool STATS>
+// FLAT = the scene has so few triangles (P.flat_count <= 16) that no hierarchy is walked: a traversing
+// lane tests every triangle, the records are fetched with SCALAR loads (one s_load per triangle per
+// wave, operands broadcast from SGPRs, no vector memory traffic and no LDS stack), and the whole walk
+// is one block of the state machine, so lanes re-synchronise by themselves.
+template <bool STATS, bool FLAT>
 __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel(const RenderParams P)
 {
-    __shared__ int lds_stack[PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
+    __shared__ int lds_stack[FLAT ? 1 : PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
     if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
 
     const int tid = threadIdx.x;
@@ -354,6 +359,9 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     Walk W;
     W.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0);
     W.occl_tri = -1; W.occl_limit = 0.0f;
+    Walk WS;                        // FLAT only: the shadow ray, tested in the same pass as the bounce ray
+    WS.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0);
+    WS.occl_tri = -1; WS.occl_limit = 0.0f;
     v3 L = V(0.0f, 0.0f, 0.0f), T = V(1.0f, 1.0f, 1.0f);
     v3 Tdi = V(0.0f, 0.0f, 0.0f), nextDir = V(0.0f, 0.0f, 1.0f);
     int depth = 0, iter = 0;
@@ -376,6 +384,25 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
         st = sample < s_count ? ST_GEN : ST_DONE;                                                 \
     } while (0)
 
+    // a finished walk: shadow rays resolve DirectIllumimation's visibility and roll into the sampled
+    // bounce; bounce rays end the path on a miss or queue for shading
+#define PTK_WALK_DONE()                                                                           \
+    do {                                                                                          \
+        if (STATS) cnt.rays++;                                                                    \
+        ray++;                                                                                    \
+        const bool hit_ = W.best.tri != PTK_NOHIT;                                                \
+        if (W.occl_tri >= 0)                                                                      \
+        {                                                                                         \
+            /* pathtracer.cpp:522-526: lit unless something else is closest */                    \
+            if (STATS) cnt.shadow++;                                                              \
+            if (!(hit_ && W.best.tri != W.occl_tri)) L = add(L, Tdi);                             \
+            W.occl_tri = -1;                                                                      \
+            W.begin(W.ro, nextDir, P.num_nodes);                                                  \
+        }                                                                                         \
+        else if (!hit_) PTK_FINISH_PATH();              /* :550 miss -> black */                  \
+        else st = ST_SHADE;                                                                       \
+    } while (0)
+
     int debt_shade = 0, debt_gen = 0;      // wave-uniform: lane-iterations wasted by parked lanes
     for (;;)
     {
@@ -395,7 +422,49 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
         // rays shade small batches early instead of idling - measured optimum in both regimes.
         bool run_shade = n_trav == 0 && n_shade >= n_gen && n_shade > 0;
         bool run_gen = n_trav == 0 && !run_shade;
-        if (n_trav > 0)
+        if (FLAT)
+        {
+            // every block is one complete unit of work for a lane: run the one most lanes wait for
+            // (weights in eighths: a cheap block may run with fewer lanes than an expensive one)
+            const int sc_trav = n_trav * 8, sc_shade = n_shade * P.flat_shade_w, sc_gen = n_gen * P.flat_gen_w;
+            if (n_trav > 0 && sc_trav >= sc_shade && sc_trav >= sc_gen)
+            {
+                if (STATS && lane == 0) { cnt.walk_iters++; cnt.walk_lanes += (uint32_t)n_trav; }
+                if (st == ST_TRAV)
+                {
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    typedef const __attribute__((address_space(4))) f4v* cf4;        // constant address space -> s_load
+                    const cf4 ct = (cf4)(uintptr_t)P.tris;
+                    // both rays of a diffuse bounce in one pass over the triangles: the shadow ray
+                    // (ray number `ray`) and the sampled bounce (`ray + 1`), pathtracer.cpp:638 / :724
+                    const bool shadow = WS.occl_tri >= 0;
+                    const uint32_t bounce_ray = shadow ? ray + 1u : ray;
+                    bool stop = !shadow;
+                    for (int k = 0; k < P.flat_count; k++)
+                    {
+                        const f4v a0 = ct[k * TRI_F4], a1 = ct[k * TRI_F4 + 1], a2 = ct[k * TRI_F4 + 2];
+                        const float4 t0 = make_float4(a0.x, a0.y, a0.z, a0.w), t1 = make_float4(a1.x, a1.y, a1.z, a1.w),
+                                     t2 = make_float4(a2.x, a2.y, a2.z, a2.w);
+                        (void)tri_test<STATS>(P, W, t0, t1, t2, rng, bounce_ray, cnt);
+                        if (!stop) stop = tri_test<STATS>(P, WS, t0, t1, t2, rng, ray, cnt);
+                    }
+                    if (shadow)
+                    {
+                        // DirectIllumimation visibility (pathtracer.cpp:522-526): lit unless something else is closest
+                        if (STATS) { cnt.rays++; cnt.shadow++; }
+                        if (!(WS.best.tri != PTK_NOHIT && WS.best.tri != WS.occl_tri)) L = add(L, Tdi);
+                        WS.occl_tri = -1;
+                        ray++;
+                    }
+                    W.node = NODE_EXIT;
+                    PTK_WALK_DONE();
+                }
+                continue;
+            }
+            run_shade = n_shade > 0 && (sc_shade >= sc_gen || n_gen == 0);
+            run_gen = !run_shade;
+        }
+        else if (n_trav > 0)
         {
             // ---- BVH walk ----
             do
@@ -404,23 +473,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
                 if (st == ST_TRAV)
                 {
                     walk_step<STATS, PTK_TRACE_BLOCK>(P, W, rng, ray, stack, cnt);
-                    if (W.done())
-                    {
-                        if (STATS) cnt.rays++;
-                        ray++;
-                        const bool hit = W.best.tri != PTK_NOHIT;
-                        if (W.occl_tri >= 0)
-                        {
-                            // DirectIllumimation visibility, pathtracer.cpp:522-526: lit unless something
-                            // else is closest; then continue with the sampled bounce from the same origin
-                            if (STATS) cnt.shadow++;
-                            if (!(hit && W.best.tri != W.occl_tri)) L = add(L, Tdi);
-                            W.occl_tri = -1;
-                            W.begin(W.ro, nextDir, P.num_nodes);
-                        }
-                        else if (!hit) PTK_FINISH_PATH();              // :550 miss -> black
-                        else st = ST_SHADE;
-                    }
+                    if (W.done()) PTK_WALK_DONE();
                 }
                 const int nt = __popcll(__ballot(st == ST_TRAV));
                 const int ns = __popcll(__ballot(st == ST_SHADE));
@@ -617,10 +670,20 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
                                 v3 lColor = V(l1.w, l2.w, l3.x);
                                 v3 di = muls(mulv(lColor, diffuse), ndl);      // :530
                                 Tdi = mulv(T, di);
-                                W.occl_tri = __float_as_int(l0.w);
-                                W.occl_limit = sqrtf(dot(dl, dl)) * 0.9999f;
-                                nextDir = dir;
-                                next_rd = l;
+                                if (FLAT)
+                                {
+                                    // the shadow ray rides along with the bounce ray in the next flat pass
+                                    WS.begin(p, l, P.num_nodes);
+                                    WS.occl_tri = __float_as_int(l0.w);
+                                    WS.occl_limit = sqrtf(dot(dl, dl)) * 0.9999f;
+                                }
+                                else
+                                {
+                                    W.occl_tri = __float_as_int(l0.w);
+                                    W.occl_limit = sqrtf(dot(dl, dl)) * 0.9999f;
+                                    nextDir = dir;
+                                    next_rd = l;
+                                }
                             }
                         }
                         T = mulv(T, weight);
@@ -673,6 +736,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
             }
         }
     }
+#undef PTK_WALK_DONE
 #undef PTK_FINISH_PATH
 
     if (STATS)
@@ -803,8 +867,11 @@ void launch_trace(const RenderParams& p, int num_items, hipStream_t stream, bool
 {
     if (num_items <= 0) return;
     int blocks = (num_items + (PTK_TRACE_BLOCK / 64) - 1) / (PTK_TRACE_BLOCK / 64);
-    if (stats) hipLaunchKernelGGL(trace_kernel<true>, dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    else hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    const bool flat = p.flat_count > 0;
+    if (stats && flat) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else if (stats) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else if (flat) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
 }
 void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t stream)
 {

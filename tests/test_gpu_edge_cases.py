@@ -106,7 +106,7 @@ def test_many_spp_chunks_and_passes(ctx, oracle_mod):
     ctx.set_option("pass_bytes", 1 << 20); ctx.set_option("chunk", 5)
     ctx.reset(); ctx.render(0, 37, 5)
     again = ctx.read_accum()
-    ctx.set_option("pass_bytes", float(4 << 30)); ctx.set_option("chunk", 16)
+    ctx.set_option("pass_bytes", float(4 << 30)); ctx.set_option("chunk", 0)
     assert np.array_equal(again, got)
 
 
@@ -127,3 +127,16 @@ def test_bad_arguments_are_errors(ctx):
     with pytest.raises(ptk.PtkError):
         ctx.set_option("no_such_option", 1)
     ctx.upload_scene(a)                                        # the context stays usable
+
+
+def test_flat_and_bvh_walks_agree(ctx, oracle_mod):
+    """Scenes of <= 16 triangles take the FLAT kernel (every triangle, scalar loads, shadow + bounce ray in
+    one pass); the BVH walk must give the same accumulator bit for bit."""
+    z = load_golden("tier_s_cornell.npz")
+    arrays = scene_from_golden(z); cam = _cam(z)
+    ref, ref8, flat, flat8 = _both(ctx, oracle_mod, arrays, cam, 64, 48, 5, 9)
+    ctx.set_option("flat", 0)
+    ctx.reset(); ctx.render(0, 9, 5)
+    walk = ctx.read_accum()
+    ctx.set_option("flat", 1)
+    assert np.array_equal(flat, ref) and np.array_equal(walk, ref)
