@@ -43,12 +43,15 @@ BYTES_SAMPLE_OUT = 16        # one float4 radiance sample stored per path (trace
 BYTES_PRIMARY = 16           # primary direction, fetched once per work item (chunk of samples)
 
 
-def algorithmic_bytes_per_sample(stats: dict, chunk: int) -> float:
-    """trace_kernel: bytes one sample (one pixel x one spp) needs, from the kernel's own counts."""
+def algorithmic_bytes_per_sample(stats: dict, chunk: int, flat: bool) -> float:
+    """trace_kernel: bytes one sample (one pixel x one spp) needs, from the kernel's own counts.
+    In FLAT mode (scenes of <= 16 triangles) a triangle record is fetched once per WAVE with a scalar
+    load and broadcast, so a lane's test accounts for 48/64 bytes."""
     s = float(stats["samples"])
+    tri_bytes = BYTES_TRI / 64.0 if flat else BYTES_TRI
     return (BYTES_SAMPLE_OUT + BYTES_PRIMARY / float(chunk)
             + stats["node_visits"] / s * BYTES_NODE
-            + stats["tri_tests"] / s * BYTES_TRI
+            + stats["tri_tests"] / s * tri_bytes
             + stats["hits_shaded"] / s * (BYTES_SHADE + BYTES_MATERIAL)
             + stats["shadow_rays"] / s * BYTES_LIGHT
             + stats["tex_fetches"] / s * BYTES_TEXEL)
@@ -209,7 +212,8 @@ def main():
         stats = ctx.collect_stats(0, min(spp, 8), args.seed)
         ctx.set_tile(rank, world)
         chunk = min(spp, 32 if ntri_for_chunk <= 16 else 16)      # ptk's automatic samples per work item
-        bps = algorithmic_bytes_per_sample(stats, chunk)
+        flat = ntri_for_chunk <= 16
+        bps = algorithmic_bytes_per_sample(stats, chunk, flat)
         launch_samples = float(W) * H * spp / world
         avg_ms = float(np.mean(ev_ms))
         achieved = bps * launch_samples / (avg_ms * 1e-3) / 1e9
@@ -223,7 +227,12 @@ def main():
             "per_sample": {"rays": round(stats["rays"] / s, 3), "shadow_rays": round(stats["shadow_rays"] / s, 3),
                            "node_visits": round(stats["node_visits"] / s, 2), "tri_tests": round(stats["tri_tests"] / s, 2),
                            "hits_shaded": round(stats["hits_shaded"] / s, 3), "tex_fetches": round(stats["tex_fetches"] / s, 3)},
-            "note": "working set is cache-resident for this config: algorithmic bytes are served by L1/L2, not HBM",
+            "kernel_variant": "FLAT (no BVH walk, scalar triangle loads)" if flat else "BVH2 walk",
+            "simd_lane_utilisation": {"walk": round(stats["walk_lane_iters"] / max(1, stats["walk_wave_iters"]) / 64.0, 3),
+                                      "shade": round(stats["shade_lanes"] / max(1, stats["shade_wave_execs"]) / 64.0, 3),
+                                      "camera": round(stats["gen_lanes"] / max(1, stats["gen_wave_execs"]) / 64.0, 3)},
+            "note": "the working set of this config is cache-resident: the algorithmic bytes are served by the scalar cache / "
+                    "L1 / L2, HBM sees only `traffic`; the kernel is VALU-issue- and divergence-bound (DESIGN.md §5)",
         }
         traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
         if os.path.exists(traffic_file):

@@ -1,0 +1,23 @@
+"""Scratch: latency of the interactive loop, RenderFrame() = 1 spp + RGB8 hand-off into the caller's buffer."""
+import sys, os, tempfile, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pbrpathtracer_amd import scenes as S
+from pbrpathtracer_amd.pathtracer import PathTracer
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+pts, scene, _ = S.build_config(cfg, tempfile.mkdtemp())
+pt = PathTracer(0); pt.LoadSceneFile(pts)
+W, H = pt.GetResolution()
+out = np.zeros((H, W, 3), np.uint8); pt.SetOutImage(out)
+for _ in range(5): pt.RenderFrame()
+n = 100
+t0 = time.perf_counter()
+for _ in range(n): pt.RenderFrame()
+dt = (time.perf_counter() - t0) / n
+print(f"{cfg} {W}x{H}: RenderFrame() {dt*1e3:.3f} ms/frame = {W*H/dt/1e6:.1f} Msamples/s, samples={pt.GetSamples()}")
+pt.SetOutImage(None)
+t0 = time.perf_counter()
+for _ in range(n): pt.RenderFrame()
+pt.context().synchronize()
+dt = (time.perf_counter() - t0) / n
+print(f"   without host hand-off: {dt*1e3:.3f} ms/frame")
