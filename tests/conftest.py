@@ -13,6 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once
+    lib = os.path.join(ROOT, "pbrpathtracer_amd", "libptk.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "pbrpathtracer_amd", "csrc"), "-j4", "-s"])
 
 
 def load_golden(name):
