@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+# torch bundles its own ROCm runtime (libamdhip64 / librccl) with the same sonames as /opt/rocm's, which
+# libptk.so links: whichever is loaded first serves both.  Loading torch first keeps one consistent
+# runtime in the process for the tests that use torch.distributed next to the kernels.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
