@@ -123,3 +123,34 @@ def test_exact_pinhole_primary_cache(tmp_path, oracle_mod, cfg, kw, spp):
     ref, _ = o.render(ocam, W, H, D, 0, spp, 21)
     assert np.array_equal(cached, ref)
     pt.close()
+
+
+def test_exit_from_another_thread(tmp_path):
+    """Exit() / GetSamples() are called from the UI thread while the render thread is inside RenderFrame
+    (main.cpp:1153, :2277-2324): must be safe; work not yet started is skipped, mSamples still advances."""
+    import threading
+    import time
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer
+    pts, scene, _ = S.build_config("C4", str(tmp_path), width=640, height=360, grid=60)
+    pt = PathTracer(0); pt.LoadSceneFile(pts)
+    pt.RenderFrames(1)
+    seen = []
+    stop = threading.Event()
+
+    def ui():
+        while not stop.is_set():
+            seen.append(pt.GetSamples())
+            time.sleep(0.0005)
+    t = threading.Thread(target=ui); t.start()
+    killer = threading.Timer(0.01, pt.Exit); killer.start()
+    t0 = time.time()
+    pt.RenderFrames(2048)                                   # long enough for Exit() to land mid-render
+    dt = time.time() - t0
+    stop.set(); t.join(); killer.join()
+    assert pt.GetSamples() == 2049 and pt.LastError() == ""
+    assert np.isfinite(pt.ReadAccumulation()).all()
+    pt.ResetImage(); pt.RenderFrames(2)                     # Exit is cleared by ResetImage: rendering resumes
+    assert pt.GetSamples() == 2 and pt.ReadAccumulation().any()
+    print(f"render with Exit() after 10 ms took {dt*1e3:.1f} ms, UI polled {len(seen)} times")
+    pt.close()

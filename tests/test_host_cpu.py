@@ -178,3 +178,47 @@ def test_textured_scene_staging(tmp_path):
     assert (s["materials"]["tex"] >= 0).sum() >= 8 and s["smoothing"].sum() > 0
     assert (s["materials"]["type"] == 1).sum() == 2
     pt.close()
+
+
+def test_obj_reader_subset(tmp_path):
+    """OBJ features the loader promises (tinyobj subset, pathtracer.cpp:41-145): quads and polygons
+    (fan-triangulated), negative indices, v//vn and v/vt forms, `g` groups as elements, smoothing groups,
+    faces before any group, CRLF line ends."""
+    from pbrpathtracer_amd.pathtracer import PathTracer
+    obj = tmp_path / "m.obj"
+    obj.write_bytes(b"\r\n".join([
+        b"v 0 0 0", b"v 1 0 0", b"v 1 1 0", b"v 0 1 0", b"v 0 0 1",
+        b"vt 0 0", b"vt 1 0", b"vt 1 1", b"vt 0 1",
+        b"vn 0 0 1",
+        b"f 1 2 3",                          # before any group: element with empty name
+        b"g quad", b"s 1",
+        b"f 1/1/1 2/2/1 3/3/1 4/4/1",        # quad -> 2 triangles, smoothing group 1
+        b"o penta", b"s off",
+        b"f -5//1 -4//1 -3//1 -2//1 -1//1",  # negative indices, pentagon -> 3 triangles
+        b"g empty_group",                    # no faces: does not become an element
+        b"g last",
+        b"f 1/1 2/2 5/3", b""]))
+    pt = PathTracer()
+    pt.LoadObject(str(obj))
+    assert pt.GetLoadedObjects() == [4]
+    assert pt.GetTriangleCount() == 1 + 2 + 3 + 1
+    s = pt.StagedScene()
+    assert list(s["material"]) == [0, 1, 1, 2, 2, 2, 3]
+    assert list(s["smoothing"]) == [0, 1, 1, 0, 0, 0, 0]
+    # x is negated on load (pathtracer.cpp:74), v flipped (pathtracer.cpp:88)
+    assert np.allclose(s["verts"][0], [0, 0, 0, -1, 0, 0, -1, 1, 0])
+    assert np.allclose(s["uvs"][1], [0, 1, 1, 1, 1, 0])
+    assert np.allclose(s["normals"][1][:3], [0, 0, 1])
+    # pentagon fan: (v1 v2 v3) (v1 v3 v4) (v1 v4 v5)
+    assert np.allclose(s["verts"][3][:3], [0, 0, 0]) and np.allclose(s["verts"][5][6:9], [0, 0, 1])
+    pt.LoadObject(str(tmp_path / "does_not_exist.obj"))      # parse failure is silently ignored (:47)
+    assert pt.GetLoadedObjects() == [4]
+    pt.ClearScene()
+    assert pt.GetTriangleCount() == 0 and pt.GetLoadedObjects() == []
+    pt.close()
+
+
+def test_unorm8_double_product_is_exact():
+    """The kernel computes byte/255.0f as (float)((double)b * (1.0/255.0)) (ptk_kernels.hip `unorm8`)."""
+    b = np.arange(256, dtype=np.uint32)
+    assert np.array_equal(b.astype(np.float32) / np.float32(255.0), (b.astype(np.float64) * (1.0 / 255.0)).astype(np.float32))
