@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (default: the config's spp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--force-exchange", action="store_true", help="run the exchange step even at N=1 (rehearsal of the N>1 path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,19 +159,23 @@ def main():
     # the kernel renders into a torch-owned accumulator on torch's current stream, so the exchange
     # step (torch.distributed -> RCCL) is ordered behind the render without host synchronisation
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
-    gathered = torch.zeros_like(accum) if world > 1 else None
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.bind_accum(accum.data_ptr())
     ctx.reset()
 
-    from pbrpathtracer_amd.distributed import gather_accumulator
+    from pbrpathtracer_amd.distributed import AccumulatorExchange
+    exchange = AccumulatorExchange(accum, dst=0) if (world > 1 or args.force_exchange) else None
 
     def step(first):
         ctx.render(first, spp, args.seed)
-        if world > 1:
-            gather_accumulator(accum, out=gathered, dst=0)         # tiles of other ranks are zero: a gather
+        if exchange is not None:
+            # snapshot + RCCL reduce on a side stream: the collective of step k overlaps the trace
+            # kernel of step k+1 (tiles of other ranks are exact zeros, so the sum is a gather)
+            exchange.start()
 
     def fence():
+        if exchange is not None:
+            exchange.wait()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -211,7 +216,13 @@ def main():
         ctx.set_tile(0, 1)
         stats = ctx.collect_stats(0, min(spp, 8), args.seed)
         ctx.set_tile(rank, world)
-        chunk = min(spp, 32 if ntri_for_chunk <= 16 else 16)      # ptk's automatic samples per work item
+        # ptk's automatic samples per work item (ptk_api.hip run_passes)
+        from pbrpathtracer_amd.distributed import owned_tile_count
+        per_item = spp * owned_tile_count(W, H, rank, world) * 4.0 / 49152.0
+        chunk, max_chunk = 4, (32 if ntri_for_chunk <= 16 else 16)
+        while chunk * 2 <= max_chunk and chunk * 2 <= per_item:
+            chunk *= 2
+        chunk = min(chunk, spp)
         flat = ntri_for_chunk <= 16
         bps = algorithmic_bytes_per_sample(stats, chunk, flat)
         launch_samples = float(W) * H * spp / world

@@ -199,8 +199,19 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
     c->last_passes = 0; c->last_launches = 0;
     if (tiles == 0) return PTK_OK;
     const size_t per_sample = (size_t)tiles * 4 * 64 * sizeof(float4);
-    // longer chunks amortise the end-of-chunk tail; the FLAT walk is short and uniform so its tail is cheap
-    const int chunk_opt = c->opt_chunk > 0 ? c->opt_chunk : (p.flat_count > 0 ? 32 : 16);
+    // Samples per work item: longer chunks amortise the end-of-chunk tail (the FLAT walk is short and
+    // uniform, so it affords 32; the BVH walk 16), but a launch must still consist of many more work
+    // items than the 4096 wave slots of the chip or its duration degenerates to that of its slowest
+    // item - which is what a rank of an 8-GPU job would see with its 1/8 of the tiles.  Aim for >= 48 k
+    // items (measured optimum at 1/4 and 1/8 of the C2 frame), never below 4 samples per item.
+    int chunk_opt = c->opt_chunk;
+    if (chunk_opt <= 0)
+    {
+        const int max_chunk = p.flat_count > 0 ? 32 : 16;
+        const double per_item = (double)spp * (double)tiles * 4.0 / 49152.0;
+        chunk_opt = 4;
+        while (chunk_opt * 2 <= max_chunk && chunk_opt * 2 <= per_item) chunk_opt *= 2;
+    }
     uint32_t max_pass = (uint32_t)std::max<size_t>(1, c->opt_pass_bytes / per_sample);
     if (max_pass > (uint32_t)chunk_opt) max_pass -= max_pass % (uint32_t)chunk_opt;
     uint32_t done = 0;

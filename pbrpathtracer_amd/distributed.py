@@ -42,3 +42,47 @@ def gather_accumulator(local, out=None, dst: int = 0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(out, dst=dst, op=dist.ReduceOp.SUM)
     return out
+
+
+class AccumulatorExchange:
+    """The exchange step overlapped with rendering: `start()` snapshots the local accumulator and
+    launches the reduce on a side stream, so the collective of batch k runs while the trace kernel of
+    batch k+1 (which does not touch the accumulator) is already on the GPU; the render stream only
+    waits for the 11-25 MB device-to-device snapshot.  `wait()` orders the render stream behind the last
+    collective; `result` holds the gathered image on `dst`.  On CPU tensors (gloo) it is synchronous."""
+
+    def __init__(self, local, dst: int = 0):
+        import torch
+        self.local = local
+        self.dst = dst
+        self.result = torch.empty_like(local)
+        self.cuda = local.is_cuda
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=local.device)
+            self.rendered = torch.cuda.Event()
+            self.copied = torch.cuda.Event()
+
+    def start(self):
+        import torch
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not self.cuda:
+            self.result.copy_(self.local)
+            if multi:
+                dist.reduce(self.result, dst=self.dst, op=dist.ReduceOp.SUM)
+            return
+        main = torch.cuda.current_stream(self.local.device)
+        self.rendered.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.rendered)
+            self.result.copy_(self.local, non_blocking=True)
+            self.copied.record(self.side)
+            if multi:
+                dist.reduce(self.result, dst=self.dst, op=dist.ReduceOp.SUM)
+        main.wait_event(self.copied)          # the next accumulate_kernel may overwrite `local` from here on
+
+    def wait(self):
+        import torch
+        if self.cuda:
+            torch.cuda.current_stream(self.local.device).wait_stream(self.side)
+        return self.result

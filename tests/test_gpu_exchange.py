@@ -80,9 +80,20 @@ def test_torch_distributed_path_world_1():
         out = gather_accumulator(accum, dst=0)
         dist.barrier(); torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().reshape(48, 80, 3), own)
-        # a second batch keeps accumulating in the bound buffer
+        # a second batch keeps accumulating in the bound buffer; overlapped exchange object as in bench.py
+        from pbrpathtracer_amd.distributed import AccumulatorExchange
+        ex = AccumulatorExchange(accum, dst=0)
         c.render(5, 3, 11)
-        torch.cuda.synchronize()
+        ex.start()
+        c.render(8, 2, 11)                                    # next batch is enqueued while the exchange runs
+        res = ex.wait(); torch.cuda.synchronize()
+        c3 = _ctx(); c3.reset(); c3.render(0, 8, 11)
+        assert np.array_equal(res.cpu().numpy().reshape(48, 80, 3), c3.read_accum())     # snapshot after 8 samples
+        c3.close()
+        c2 = _ctx(); c2.reset(); c2.render(0, 10, 11)
+        assert np.array_equal(accum.cpu().numpy().reshape(48, 80, 3), c2.read_accum())
+        c.close(); c2.close()
+        return
         c2 = _ctx(); c2.reset(); c2.render(0, 8, 11)
         assert np.array_equal(accum.cpu().numpy().reshape(48, 80, 3), c2.read_accum())
         c.close(); c2.close()

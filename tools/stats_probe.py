@@ -13,6 +13,8 @@ for kv in os.environ.get('PTK_OPTS','').split(','):
     if '=' in kv:
         k,v=kv.split('='); c.set_option(k, float(v))
 W,H = pt.GetResolution()
+if os.environ.get('PTK_TILE'):
+    r,w = map(int, os.environ['PTK_TILE'].split(',')); c.set_tile(r,w); print('tile',r,w)
 best=1e9
 for rep in range(3):
     c.reset(); c.render(0, spp, 1); c.synchronize(); tm, am = c.last_kernel_ms(); best=min(best,tm+am)
