@@ -56,6 +56,9 @@ const ptk_scene_desc* pth_staged_scene(pth_tracer* t);    /* flat arrays of the 
 int  pth_load_scene_file(pth_tracer* t, const char* pts_path);   /* 0 ok, <0 parse error (text via pth_last_error) */
 int  pth_pts_roundtrip(const char* in_path, const char* out_path); /* read_pts + write_pts, 0 ok */
 
+/* ExportAt (main.cpp:760-771): write the bottom-up RGB8 hand-off buffer as a top-down PNG; 1 on success */
+int  pth_export_png(const char* path, const uint8_t* rgb8_bottom_up, int w, int h);
+
 /* host-only probes (no GPU): glm-0.9.3.1-compatible TRS / Euler camera, Triangle::Init, Image */
 void pth_trs_matrix(const float loc[3], const float rot_deg[3], const float scl[3], float out16[16]);
 void pth_euler_camera(const float rot_deg[3], float out6[6]);

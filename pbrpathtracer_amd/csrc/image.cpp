@@ -274,3 +274,48 @@ glm::vec4 Image::tex2D(const glm::vec2& uv)
     const unsigned char* p = mData + (4 * (cy * mWidth + cx));
     return glm::vec4((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f);
 }
+
+// PNG export of the RGB8 hand-off buffer: the reference's ExportAt (main.cpp:760-771) writes texData with
+// stbi_flip_vertically_on_write(true), i.e. the bottom-up buffer becomes a top-down image.  Stored
+// (filter 0) scanlines, zlib-compressed; 8-bit RGB, no alpha.
+static void put_be32(std::vector<unsigned char>& v, uint32_t x)
+{
+    v.push_back((unsigned char)(x >> 24)); v.push_back((unsigned char)(x >> 16));
+    v.push_back((unsigned char)(x >> 8)); v.push_back((unsigned char)x);
+}
+static void put_chunk(std::vector<unsigned char>& out, const char* type, const std::vector<unsigned char>& body)
+{
+    put_be32(out, (uint32_t)body.size());
+    size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), body.begin(), body.end());
+    uint32_t crc = (uint32_t)crc32(0L, out.data() + start, (uInt)(out.size() - start));
+    put_be32(out, crc);
+}
+bool ptk_write_png_rgb8_bottom_up(const char* path, const unsigned char* rgb, int w, int h)
+{
+    if (!path || !rgb || w <= 0 || h <= 0) return false;
+    std::vector<unsigned char> raw((size_t)h * ((size_t)w * 3 + 1));
+    for (int y = 0; y < h; y++)
+    {
+        unsigned char* row = &raw[(size_t)y * ((size_t)w * 3 + 1)];
+        row[0] = 0;
+        std::memcpy(row + 1, rgb + (size_t)(h - 1 - y) * w * 3, (size_t)w * 3);     // vertical flip
+    }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<unsigned char> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+    comp.resize(clen);
+    std::vector<unsigned char> out = { 137, 80, 78, 71, 13, 10, 26, 10 };
+    std::vector<unsigned char> ihdr;
+    put_be32(ihdr, (uint32_t)w); put_be32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    put_chunk(out, "IHDR", ihdr);
+    put_chunk(out, "IDAT", comp);
+    put_chunk(out, "IEND", std::vector<unsigned char>());
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return false;
+    size_t n = std::fwrite(out.data(), 1, out.size(), f);
+    std::fclose(f);
+    return n == out.size();
+}

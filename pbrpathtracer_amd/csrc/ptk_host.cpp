@@ -9,6 +9,8 @@
 
 using namespace ptkhost;
 
+bool ptk_write_png_rgb8_bottom_up(const char* path, const unsigned char* rgb, int w, int h);   // image.cpp
+
 struct pth_tracer {
     PathTracer pt;
     std::string error;
@@ -120,6 +122,10 @@ void pth_triangle_init(const float* in, float* out9)
     for (int k = 0; k < 3; k++) { for (int a = 0; a < 3; a++) t.v[k][a] = in[k * 3 + a]; t.uv[k][0] = in[9 + k * 2]; t.uv[k][1] = in[10 + k * 2]; }
     triangle_init(t);
     for (int a = 0; a < 3; a++) { out9[a] = t.normal[a]; out9[3 + a] = t.tangent[a]; out9[6 + a] = t.bitangent[a]; }
+}
+int pth_export_png(const char* path, const uint8_t* rgb8_bottom_up, int w, int h)
+{
+    return ptk_write_png_rgb8_bottom_up(path, rgb8_bottom_up, w, h) ? 1 : 0;
 }
 static Image g_img;
 int pth_image_load(const char* file, int* w, int* h)

@@ -33,6 +33,7 @@ HOST_SYMBOLS = [
     "pth_render_frame", "pth_exit", "pth_set_seed", "pth_set_tile", "pth_render_frames", "pth_read_accum",
     "pth_last_error", "pth_context", "pth_staged_scene", "pth_load_scene_file", "pth_pts_roundtrip",
     "pth_trs_matrix", "pth_euler_camera", "pth_triangle_init", "pth_image_load", "pth_image_data", "pth_image_tex2d",
+    "pth_export_png",
 ]
 
 _bound = False
@@ -77,6 +78,7 @@ def lib() -> C.CDLL:
     L.pth_image_load.restype = i32; L.pth_image_load.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32)]
     L.pth_image_data.restype = None; L.pth_image_data.argtypes = [vp]
     L.pth_image_tex2d.restype = None; L.pth_image_tex2d.argtypes = [f32, f32, _f]
+    L.pth_export_png.restype = i32; L.pth_export_png.argtypes = [C.c_char_p, vp, i32, i32]
     _bound = True
     return L
 
@@ -255,6 +257,14 @@ def image_tex2d(u: float, v: float) -> np.ndarray:
     out = np.zeros(4, np.float32)
     lib().pth_image_tex2d(u, v, _fp(out))
     return out
+
+
+def export_png(path: str, rgb8_bottom_up: np.ndarray) -> bool:
+    """ExportAt (main.cpp:760-771): the bottom-up RGB8 buffer as a top-down PNG."""
+    a = np.ascontiguousarray(rgb8_bottom_up, np.uint8)
+    h, w, c = a.shape
+    assert c == 3
+    return bool(lib().pth_export_png(path.encode(), a.ctypes.data, w, h))
 
 
 def camera_from_scene(scene):

@@ -222,3 +222,14 @@ def test_unorm8_double_product_is_exact():
     """The kernel computes byte/255.0f as (float)((double)b * (1.0/255.0)) (ptk_kernels.hip `unorm8`)."""
     b = np.arange(256, dtype=np.uint32)
     assert np.array_equal(b.astype(np.float32) / np.float32(255.0), (b.astype(np.float64) * (1.0 / 255.0)).astype(np.float32))
+
+
+def test_png_export_flips_to_top_down(tmp_path):
+    """ExportAt writes texData with stbi_flip_vertically_on_write(true) (main.cpp:765-767)."""
+    from pbrpathtracer_amd import pathtracer as P
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (7, 11, 3), dtype=np.uint8)        # bottom-up buffer
+    p = str(tmp_path / "o.png")
+    assert P.export_png(p, img)
+    back = P.image_load(p)                                         # our decoder reads it back top-down
+    assert np.array_equal(back[..., :3], img[::-1]) and (back[..., 3] == 255).all()
