@@ -209,13 +209,14 @@ struct Walk {
 // Candidate test of one triangle record: Hit's leaf branch (pathtracer.cpp:463-489) = Moeller-Trumbore
 // + order-independent closest rule + stochastic opacity.  Returns true when the walk can stop (an
 // occluder decided a shadow ray).
+// FLAT pass variant with the reference's early returns: there the whole wave tests the same triangle, so
+// a rejection usually holds for every lane and the branch skips real work.
 template <bool STATS, class PT>
-__device__ __forceinline__ bool tri_test(const PT& P, Walk& W, float4 t0, float4 t1, float4 t2, const Rng& rng,
-                                         uint32_t ray, Counters& cnt)
+__device__ __forceinline__ bool tri_test_early(const PT& P, Walk& W, float4 t0, float4 t1, float4 t2, const Rng& rng,
+                                               uint32_t ray, Counters& cnt)
 {
     const v3 ro = W.ro, rd = W.rd;
     if (STATS) cnt.tris++;
-    // Moeller-Trumbore, PathTracer::IntersectTriangle pathtracer.cpp:373-409
     v3 v0 = V(t0.x, t0.y, t0.z);
     v3 edge1 = V(t0.w, t1.x, t1.y);
     v3 edge2 = V(t1.z, t1.w, t2.x);
@@ -236,7 +237,6 @@ __device__ __forceinline__ bool tri_test(const PT& P, Walk& W, float4 t0, float4
     int otex = __float_as_int(t2.z);
     if (otex >= 0)
     {
-        // stochastic opacity, pathtracer.cpp:469-476 (GetUV :533-536)
         const float4* sp4 = P.shade + (size_t)tri * SHADE_F4;
         float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
         float w = 1.0f - u - v;
@@ -250,21 +250,72 @@ __device__ __forceinline__ bool tri_test(const PT& P, Walk& W, float4 t0, float4
     return W.occl_tri >= 0 && tri != W.occl_tri && t < W.occl_limit;
 }
 
+template <bool STATS, class PT>
+__device__ __forceinline__ bool tri_test(const PT& P, Walk& W, float4 t0, float4 t1, float4 t2, const Rng& rng,
+                                         uint32_t ray, Counters& cnt)
+{
+    const v3 ro = W.ro, rd = W.rd;
+    if (STATS) cnt.tris++;
+    // Moeller-Trumbore, PathTracer::IntersectTriangle pathtracer.cpp:373-409.  The reference returns
+    // early after each rejection test; here every quantity is computed and the SAME tests (in their
+    // negated form, so NaNs fall through exactly as they do there) are AND-ed: identical results for
+    // every accepted hit, no divergent branches in the hot loop.
+    v3 v0 = V(t0.x, t0.y, t0.z);
+    v3 edge1 = V(t0.w, t1.x, t1.y);
+    v3 edge2 = V(t1.z, t1.w, t2.x);
+    v3 h = cross(rd, edge2);
+    float a = dot(edge1, h);
+    float f = 1.0f / a;
+    v3 s = sub(ro, v0);
+    float u = f * dot(s, h);
+    v3 q = cross(s, edge1);
+    float v = f * dot(rd, q);
+    float t = f * dot(edge2, q);
+    int tri = __float_as_int(t2.y);
+    bool ok = !(fabsf(a) < PTK_EPS) & !(u < 0.0f) & !(u > 1.0f) & !(v < 0.0f) & !(u + v > 1.0f) & (t > PTK_EPS);
+    ok = ok & ((t < W.best.t) | ((t == W.best.t) & (tri < W.best.tri)));
+    int otex = __float_as_int(t2.z);
+    if (ok && otex >= 0)
+    {
+        // stochastic opacity, pathtracer.cpp:469-476 (GetUV :533-536)
+        const float4* sp4 = P.shade + (size_t)tri * SHADE_F4;
+        float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
+        float w = 1.0f - u - v;
+        float ux = w * s1.x + u * s1.z + v * s2.x;
+        float uy = w * s1.y + u * s1.w + v * s2.y;
+        float op = tex2d_r(P, otex, ux, uy);
+        if (STATS) cnt.tex++;
+        ok = rng.opacity(ray, (uint32_t)tri) < op;
+    }
+    W.best.tri = ok ? tri : W.best.tri;
+    W.best.t = ok ? t : W.best.t;
+    W.best.u = ok ? u : W.best.u;
+    W.best.v = ok ? v : W.best.v;
+    return ok & (W.occl_tri >= 0) & (tri != W.occl_tri) & (t < W.occl_limit);
+}
+
 // One unit of BVH work per call: EITHER one interior node (two slab tests) OR one triangle of the
 // pending leaf.  Lanes of a wave therefore never wait for another lane's 4-triangle leaf: every
-// traversing lane does one unit per wave iteration, whichever kind it needs.
+// traversing lane does one unit per wave iteration, whichever kind it needs.  Control flow is kept
+// to two arms + one shared pop; the choices inside an arm are selects.
 template <bool STATS, int STRIDE, class PT>
 __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, uint32_t ray, int* stack, Counters& cnt)
 {
-    if (W.tri_left > 0)
+    bool need_pop;
+    int next = W.node;
+    const bool was_tri = W.tri_left > 0;
+    if (was_tri)
     {
         const float4* tp = P.tris + (size_t)W.tri_next * TRI_F4;
         float4 t0 = ldg4(tp), t1 = ldg4(tp + 1), t2 = ldg4(tp + 2);
         W.tri_next++; W.tri_left--;
-        if (tri_test<STATS>(P, W, t0, t1, t2, rng, ray, cnt)) { W.sp = 0; W.tri_left = 0; }
-        if (W.tri_left == 0) W.template pop<STRIDE>(stack);
+        const bool stop = tri_test<STATS>(P, W, t0, t1, t2, rng, ray, cnt);
+        W.sp = stop ? 0 : W.sp;
+        W.tri_left = stop ? 0 : W.tri_left;
+        need_pop = W.tri_left == 0;
     }
-    else if (W.node >= 0)
+    else if (W.node < 0) return;        // NODE_EXIT (an empty scene starts finished): nothing to do
+    else
     {
         const float4* np = P.nodes + (size_t)W.node * NODE_F4;
         float4 q0 = ldg4(np), q1 = ldg4(np + 1), q2 = ldg4(np + 2), q3 = ldg4(np + 3);
@@ -278,20 +329,25 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
         float tfl = fminf(fminf(fmaxf(x0.x, x1.x), fmaxf(y0.x, y1.x)), fmaxf(z0.x, z1.x));
         float tnr = fmaxf(fmaxf(fminf(x0.y, x1.y), fminf(y0.y, y1.y)), fminf(z0.y, z1.y));
         float tfr = fminf(fminf(fmaxf(x0.y, x1.y), fmaxf(y0.y, y1.y)), fmaxf(z0.y, z1.y));
-        bool hl = (tnl <= tfl * 1.000001f) && (tfl >= 0.0f) && (tnl <= W.best.t);
-        bool hr = (tnr <= tfr * 1.000001f) && (tfr >= 0.0f) && (tnr <= W.best.t);
-        int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-        if (hl && hr)
+        const bool hl = (tnl <= tfl * 1.000001f) & (tfl >= 0.0f) & (tnl <= W.best.t);
+        const bool hr = (tnr <= tfr * 1.000001f) & (tfr >= 0.0f) & (tnr <= W.best.t);
+        const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+        const bool lfirst = tnl <= tnr;
+        const bool both = hl & hr;
+        if (both)
         {
-            bool lfirst = tnl <= tnr;
-            stack[W.sp * STRIDE] = lfirst ? right : left;
+            stack[W.sp * STRIDE] = lfirst ? right : left;       // far child waits on the stack
             W.sp++;
-            W.set_node(lfirst ? left : right);
         }
-        else if (hl) W.set_node(left);
-        else if (hr) W.set_node(right);
-        else W.template pop<STRIDE>(stack);
+        next = both ? (lfirst ? left : right) : (hl ? left : right);
+        need_pop = !(hl | hr);
     }
+    if (need_pop)
+    {
+        next = NODE_EXIT;
+        if (W.sp > 0) { W.sp--; next = stack[W.sp * STRIDE]; }
+    }
+    if (!was_tri | need_pop) W.set_node(next);      // (a leaf with triangles left keeps its pending range)
 }
 
 // hemisphere / lobe sampler, pathtracer.cpp:606-611 (:618-623 lobe form): see oracle sample_about()
@@ -445,8 +501,8 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
                         const f4v a0 = ct[k * TRI_F4], a1 = ct[k * TRI_F4 + 1], a2 = ct[k * TRI_F4 + 2];
                         const float4 t0 = make_float4(a0.x, a0.y, a0.z, a0.w), t1 = make_float4(a1.x, a1.y, a1.z, a1.w),
                                      t2 = make_float4(a2.x, a2.y, a2.z, a2.w);
-                        (void)tri_test<STATS>(P, W, t0, t1, t2, rng, bounce_ray, cnt);
-                        if (!stop) stop = tri_test<STATS>(P, WS, t0, t1, t2, rng, ray, cnt);
+                        (void)tri_test_early<STATS>(P, W, t0, t1, t2, rng, bounce_ray, cnt);
+                        if (!stop) stop = tri_test_early<STATS>(P, WS, t0, t1, t2, rng, ray, cnt);
                     }
                     if (shadow)
                     {
