@@ -302,10 +302,61 @@ def tier_s(ref: Ref, tmp: str):
              rgb8=ref.rgb8(res, res), **scene_arrays_dict(arr))
 
 
+
+def tier_k_images(ref: Ref, tmp: str):
+    """Texture ingest (Image::Load -> stbi_load(..., 4), image.cpp:38-61): encoded files + the RGBA8 the
+    reference decodes them to.  Files are produced with Pillow; the expected texels come from the
+    reference's stb_image."""
+    import io
+    from PIL import Image as PI
+    rng = np.random.default_rng(77)
+    yy, xx = np.mgrid[0:37, 0:53]
+    base = np.stack([(xx * 5) % 256, (yy * 7) % 256, ((xx + yy) * 3) % 256], -1).astype(np.uint8)
+    base[10:20, 15:40] = rng.integers(0, 256, (10, 25, 3), dtype=np.uint8)
+    grey = base[..., 0]
+    cases = []
+
+    def add(name, img, fmt, **kw):
+        buf = io.BytesIO(); img.save(buf, fmt, **kw); cases.append((name, buf.getvalue()))
+    rgb = PI.fromarray(base, "RGB")
+    add("jpg_444_q90", rgb, "JPEG", quality=90, subsampling=0)
+    add("jpg_422_q75", rgb, "JPEG", quality=75, subsampling=1)
+    add("jpg_420_q60_opt", rgb, "JPEG", quality=60, subsampling=2, optimize=True)
+    add("jpg_420_q30", rgb, "JPEG", quality=30, subsampling=2)
+    add("jpg_grey_q80", PI.fromarray(grey, "L"), "JPEG", quality=80)
+    add("jpg_420_restart", rgb, "JPEG", quality=85, subsampling=2, restart_marker_blocks=2)
+    add("jpg_tiny_1x1", PI.fromarray(base[:1, :1], "RGB"), "JPEG", quality=90)
+    add("jpg_odd_17x9_420", PI.fromarray(base[:9, :17], "RGB"), "JPEG", quality=70, subsampling=2)
+    add("jpg_q100_444", rgb, "JPEG", quality=100, subsampling=0)
+    add("png_rgb", rgb, "PNG")
+    add("png_rgba", PI.fromarray(np.dstack([base, (xx * 4 % 256).astype(np.uint8)]), "RGBA"), "PNG")
+    add("png_grey", PI.fromarray(grey, "L"), "PNG")
+    add("png_grey_alpha", PI.fromarray(np.dstack([grey, 255 - grey]), "LA"), "PNG")
+    add("png_palette", rgb.quantize(16), "PNG")
+    add("png_16bit_grey", PI.fromarray((grey.astype(np.uint16) * 257), "I;16"), "PNG")
+    add("png_1bit", PI.fromarray(grey > 128).convert("1"), "PNG")
+    out = {}
+    names = []
+    for name, data in cases:
+        p = os.path.join(tmp, name)
+        with open(p, "wb") as f:
+            f.write(data)
+        w = C.c_int(); h = C.c_int()
+        ok = ref.lib.ref_image_load(p.encode(), C.byref(w), C.byref(h))
+        assert ok == 1, name
+        px = np.zeros((h.value, w.value, 4), np.uint8)
+        ref.lib.ref_image_data(px.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        out["file_" + name] = np.frombuffer(data, np.uint8)
+        out["rgba_" + name] = px
+        names.append(name)
+    save("tier_k_images.npz", names=np.array(names), **out)
+
+
 def main():
     ref = Ref()
     with tempfile.TemporaryDirectory() as tmp:
         tier_k(ref, tmp)
+        tier_k_images(ref, tmp)
         tier_k_scene(ref, tmp)
         tier_t(ref, tmp)
         tier_s(ref, tmp)

@@ -2,14 +2,15 @@
 // on stb_image / stb_image_resize) with a small own decoder.  Off the per-sample path: images are
 // decoded once to RGBA8 and uploaded into the device texel atlas by PathTracer::BuildBVH.
 //
-// Formats: binary PNM (P5 / P6, maxval <= 255 or 16-bit) and non-interlaced PNG (colour types 0, 2, 3,
-// 4, 6; bit depths 1-16) through zlib.  Everything is expanded to 4 channels the way stbi_load(..., 4)
+// Formats: binary PNM (P5 / P6, maxval <= 255 or 16-bit), non-interlaced PNG (colour types 0, 2, 3, 4, 6;
+// bit depths 1-16) through zlib, and baseline / extended-sequential Huffman JPEG (grey, YCbCr, RGB).  Everything is expanded to 4 channels the way stbi_load(..., 4)
 // does (grey -> g,g,g,255; 16-bit -> high byte).  Images with a side > 1024 are reduced so the
 // longest side is 1024 (image.cpp:47-60) — with an area-average filter, not stb_image_resize's
 // Mitchell kernel: the resulting SIZE is pinned by the golden vectors, the filtered texel values are
 // "parity unpinned".
 #include <zlib.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -178,6 +179,502 @@ bool decode_png(const std::vector<unsigned char>& d, int& w, int& h, std::vector
     return true;
 }
 
+
+// ---- JPEG (baseline / extended sequential, Huffman, 8-bit) -------------------------------------------
+// Restates the decoding pipeline of the reference's stb_image 2.27 for the files it is given most often:
+// integer "ISLOW" inverse DCT with stb's scaling, stb's 2x chroma upsampling kernels (h2, v2, hv2) and
+// its fixed-point YCbCr->RGB, so decoded texels are bit-identical to stbi_load(..., 4)
+// (pinned by tests/golden/tier_k_images.npz).  Progressive and CMYK files are not supported: Load fails
+// and the texture samples as 0, like any unreadable file (image.cpp:65-66).
+struct JpegHuff {
+    unsigned char size[257];
+    unsigned short code[256];
+    unsigned char values[256];
+    int maxcode[18];
+    int delta[17];
+    bool build(const int* count)
+    {
+        int k = 0;
+        for (int i = 0; i < 16; i++)
+            for (int j = 0; j < count[i]; j++) { if (k >= 256) return false; size[k++] = (unsigned char)(i + 1); }
+        size[k] = 0;
+        int code_ = 0; k = 0;
+        for (int j = 1; j <= 16; j++)
+        {
+            delta[j] = k - code_;
+            if (size[k] == j)
+            {
+                while (size[k] == j) code[k++] = (unsigned short)code_++;
+                if (code_ - 1 >= (1 << j)) return false;
+            }
+            maxcode[j] = code_ << (16 - j);
+            code_ <<= 1;
+        }
+        maxcode[17] = 0x7fffffff;
+        return true;
+    }
+};
+
+struct JpegComp {
+    int id, h, v, tq, hd, ha, dc_pred;
+    int x, y, w2, h2;
+    std::vector<unsigned char> data;
+};
+
+struct JpegDec {
+    const unsigned char* p; const unsigned char* end;
+    uint32_t bitbuf = 0; int bitcnt = 0; int marker = 0xff; bool nomore = false;
+    JpegHuff hdc[4], hac[4];
+    unsigned short dequant[4][64];
+    JpegComp comp[4];
+    int ncomp = 0, w = 0, h = 0, h_max = 1, v_max = 1, mcu_x = 0, mcu_y = 0, restart_interval = 0, todo = 0;
+    int jfif = 0, app14 = -1, rgb = 0;
+    int scan_n = 0, order[4];
+
+    int get8() { return p < end ? *p++ : 0; }
+    int get16() { int a = get8(); return (a << 8) | get8(); }
+    void grow()
+    {
+        do
+        {
+            unsigned b = nomore ? 0 : (unsigned)get8();
+            if (b == 0xff)
+            {
+                int c = get8();
+                while (c == 0xff) c = get8();
+                if (c != 0) { marker = c; nomore = true; return; }
+            }
+            bitbuf |= b << (24 - bitcnt);
+            bitcnt += 8;
+        } while (bitcnt <= 24);
+    }
+    int decode(const JpegHuff& hf)
+    {
+        if (bitcnt < 16) grow();
+        unsigned temp = bitbuf >> 16;
+        int k;
+        for (k = 1; k <= 16; k++) if ((int)temp < hf.maxcode[k]) break;
+        if (k == 17 || k > bitcnt) return -1;
+        int c = (int)((bitbuf >> (32 - k)) & ((1u << k) - 1)) + hf.delta[k];
+        if (c < 0 || c >= 256) return -1;
+        bitcnt -= k; bitbuf <<= k;
+        return hf.values[c];
+    }
+    int extend_receive(int n)
+    {
+        if (n == 0) return 0;
+        if (bitcnt < n) grow();
+        if (bitcnt < n) return 0;
+        int sgn = (int)(bitbuf >> 31);
+        unsigned k = (bitbuf << n) | (bitbuf >> (32 - n));        // rotate left
+        bitbuf = k & ~((1u << n) - 1);
+        k &= (1u << n) - 1;
+        bitcnt -= n;
+        static const int bias[16] = { 0, -1, -3, -7, -15, -31, -63, -127, -255, -511, -1023, -2047, -4095, -8191, -16383, -32767 };
+        return (int)k + (bias[n] & (sgn - 1));
+    }
+    void reset()
+    {
+        bitbuf = 0; bitcnt = 0; nomore = false; marker = 0xff;
+        for (int i = 0; i < 4; i++) comp[i].dc_pred = 0;
+        todo = restart_interval ? restart_interval : 0x7fffffff;
+    }
+};
+
+static const unsigned char kJpegDezigzag[64 + 15] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+    63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63 };
+
+static inline unsigned char jclamp(int x) { return (unsigned char)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+
+// jidctint "ISLOW" with stb_image's fixed-point constants and rounding
+#define JF2F(x) ((int)(((x) * 4096 + 0.5)))
+#define JIDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                        \
+    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                             \
+    p2 = s2; p3 = s6;                                                                                   \
+    p1 = (p2 + p3) * JF2F(0.5411961f);                                                                  \
+    t2 = p1 + p3 * JF2F(-1.847759065f);                                                                 \
+    t3 = p1 + p2 * JF2F(0.765366865f);                                                                  \
+    p2 = s0; p3 = s4;                                                                                   \
+    t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096;                                                       \
+    x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                                             \
+    t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                                                 \
+    p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;                                             \
+    p5 = (p3 + p4) * JF2F(1.175875602f);                                                                \
+    t0 = t0 * JF2F(0.298631336f); t1 = t1 * JF2F(2.053119869f);                                         \
+    t2 = t2 * JF2F(3.072711026f); t3 = t3 * JF2F(1.501321110f);                                         \
+    p1 = p5 + p1 * JF2F(-0.899976223f); p2 = p5 + p2 * JF2F(-2.562915447f);                             \
+    p3 = p3 * JF2F(-1.961570560f); p4 = p4 * JF2F(-0.390180644f);                                       \
+    t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+
+static void jpeg_idct(unsigned char* out, int stride, const short* data)
+{
+    int val[64];
+    for (int i = 0; i < 8; i++)
+    {
+        const short* d = data + i; int* v = val + i;
+        if (d[8] == 0 && d[16] == 0 && d[24] == 0 && d[32] == 0 && d[40] == 0 && d[48] == 0 && d[56] == 0)
+        {
+            int dc = d[0] * 4;
+            v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
+        }
+        else
+        {
+            JIDCT_1D(d[0], d[8], d[16], d[24], d[32], d[40], d[48], d[56])
+            x0 += 512; x1 += 512; x2 += 512; x3 += 512;
+            v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10;
+            v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
+            v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10;
+            v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+        }
+    }
+    for (int i = 0; i < 8; i++)
+    {
+        const int* v = val + i * 8; unsigned char* o = out + i * stride;
+        JIDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
+        x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
+        o[0] = jclamp((x0 + t3) >> 17); o[7] = jclamp((x0 - t3) >> 17);
+        o[1] = jclamp((x1 + t2) >> 17); o[6] = jclamp((x1 - t2) >> 17);
+        o[2] = jclamp((x2 + t1) >> 17); o[5] = jclamp((x2 - t1) >> 17);
+        o[3] = jclamp((x3 + t0) >> 17); o[4] = jclamp((x3 - t0) >> 17);
+    }
+}
+
+static bool jpeg_block(JpegDec& z, short* data, int n)
+{
+    JpegComp& c = z.comp[n];
+    if (z.bitcnt < 16) z.grow();
+    int t = z.decode(z.hdc[c.hd]);
+    if (t < 0 || t > 15) return false;
+    std::memset(data, 0, 64 * sizeof(short));
+    int diff = t ? z.extend_receive(t) : 0;
+    int dc = c.dc_pred + diff;
+    c.dc_pred = dc;
+    data[0] = (short)(dc * z.dequant[c.tq][0]);
+    int k = 1;
+    do
+    {
+        if (z.bitcnt < 16) z.grow();
+        int rs = z.decode(z.hac[c.ha]);
+        if (rs < 0) return false;
+        int s = rs & 15, r = rs >> 4;
+        if (s == 0)
+        {
+            if (rs != 0xf0) break;
+            k += 16;
+        }
+        else
+        {
+            k += r;
+            unsigned zig = kJpegDezigzag[k++];
+            data[zig] = (short)(z.extend_receive(s) * z.dequant[c.tq][zig]);
+        }
+    } while (k < 64);
+    return true;
+}
+
+static bool jpeg_scan(JpegDec& z)
+{
+    z.reset();
+    short data[64];
+    if (z.scan_n == 1)
+    {
+        int n = z.order[0];
+        JpegComp& c = z.comp[n];
+        int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+        for (int j = 0; j < bh; j++)
+            for (int i = 0; i < bw; i++)
+            {
+                if (!jpeg_block(z, data, n)) return false;
+                jpeg_idct(&c.data[(size_t)c.w2 * j * 8 + i * 8], c.w2, data);
+                if (--z.todo <= 0)
+                {
+                    if (z.bitcnt < 24) z.grow();
+                    if (!(z.marker >= 0xd0 && z.marker <= 0xd7)) return true;
+                    z.reset();
+                }
+            }
+        return true;
+    }
+    for (int j = 0; j < z.mcu_y; j++)
+        for (int i = 0; i < z.mcu_x; i++)
+        {
+            for (int k = 0; k < z.scan_n; k++)
+            {
+                int n = z.order[k];
+                JpegComp& c = z.comp[n];
+                for (int y = 0; y < c.v; y++)
+                    for (int x = 0; x < c.h; x++)
+                    {
+                        int x2 = (i * c.h + x) * 8, y2 = (j * c.v + y) * 8;
+                        if (!jpeg_block(z, data, n)) return false;
+                        jpeg_idct(&c.data[(size_t)c.w2 * y2 + x2], c.w2, data);
+                    }
+            }
+            if (--z.todo <= 0)
+            {
+                if (z.bitcnt < 24) z.grow();
+                if (!(z.marker >= 0xd0 && z.marker <= 0xd7)) return true;
+                z.reset();
+            }
+        }
+    return true;
+}
+
+// stb_image's chroma upsampling kernels
+static const unsigned char* jres_1(unsigned char*, const unsigned char* n, const unsigned char*, int, int) { return n; }
+static const unsigned char* jres_v2(unsigned char* out, const unsigned char* n, const unsigned char* f, int w, int)
+{
+    for (int i = 0; i < w; i++) out[i] = (unsigned char)((3 * n[i] + f[i] + 2) >> 2);
+    return out;
+}
+static const unsigned char* jres_h2(unsigned char* out, const unsigned char* in, const unsigned char*, int w, int)
+{
+    if (w == 1) { out[0] = out[1] = in[0]; return out; }
+    out[0] = in[0];
+    out[1] = (unsigned char)((in[0] * 3 + in[1] + 2) >> 2);
+    int i;
+    for (i = 1; i < w - 1; i++)
+    {
+        int n = 3 * in[i] + 2;
+        out[i * 2] = (unsigned char)((n + in[i - 1]) >> 2);
+        out[i * 2 + 1] = (unsigned char)((n + in[i + 1]) >> 2);
+    }
+    out[i * 2] = (unsigned char)((in[w - 2] * 3 + in[w - 1] + 2) >> 2);
+    out[i * 2 + 1] = in[w - 1];
+    return out;
+}
+static const unsigned char* jres_hv2(unsigned char* out, const unsigned char* n, const unsigned char* f, int w, int)
+{
+    if (w == 1) { out[0] = out[1] = (unsigned char)((3 * n[0] + f[0] + 2) >> 2); return out; }
+    int t1 = 3 * n[0] + f[0], t0;
+    out[0] = (unsigned char)((t1 + 2) >> 2);
+    for (int i = 1; i < w; i++)
+    {
+        t0 = t1; t1 = 3 * n[i] + f[i];
+        out[i * 2 - 1] = (unsigned char)((3 * t0 + t1 + 8) >> 4);
+        out[i * 2] = (unsigned char)((3 * t1 + t0 + 8) >> 4);
+    }
+    out[w * 2 - 1] = (unsigned char)((t1 + 2) >> 2);
+    return out;
+}
+static const unsigned char* jres_generic(unsigned char* out, const unsigned char* n, const unsigned char*, int w, int hs)
+{
+    for (int i = 0; i < w; i++) for (int j = 0; j < hs; j++) out[i * hs + j] = n[i];
+    return out;
+}
+
+bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgba)
+{
+    if (d.size() < 4 || d[0] != 0xff || d[1] != 0xd8) return false;
+    JpegDec z;
+    z.p = d.data() + 2; z.end = d.data() + d.size();
+    for (int i = 0; i < 4; i++) { z.comp[i] = JpegComp(); }
+    bool have_frame = false, decoded = false;
+    int m = 0;
+    auto next_marker = [&]() -> int {
+        if (z.marker != 0xff) { int x = z.marker; z.marker = 0xff; return x; }
+        int x = z.get8();
+        if (x != 0xff) return 0xff;
+        while (x == 0xff && z.p < z.end) x = z.get8();
+        return x;
+    };
+    m = next_marker();
+    while (m != 0xd9)
+    {
+        if (z.p >= z.end) break;
+        if (m == 0xc0 || m == 0xc1)                               // SOF0 / SOF1
+        {
+            int Lf = z.get16(); int prec = z.get8();
+            if (prec != 8) return false;
+            z.h = z.get16(); z.w = z.get16();
+            if (z.w <= 0 || z.h <= 0 || z.w > (1 << 14) || z.h > (1 << 14)) return false;
+            z.ncomp = z.get8();
+            if (z.ncomp != 1 && z.ncomp != 3) return false;       // CMYK / YCCK not supported
+            if (Lf != 8 + 3 * z.ncomp) return false;
+            z.rgb = 0;
+            for (int i = 0; i < z.ncomp; i++)
+            {
+                static const unsigned char rgbid[3] = { 'R', 'G', 'B' };
+                z.comp[i].id = z.get8();
+                if (z.ncomp == 3 && z.comp[i].id == rgbid[i]) z.rgb++;
+                int q = z.get8();
+                z.comp[i].h = q >> 4; z.comp[i].v = q & 15;
+                z.comp[i].tq = z.get8();
+                if (z.comp[i].h < 1 || z.comp[i].h > 4 || z.comp[i].v < 1 || z.comp[i].v > 4 || z.comp[i].tq > 3) return false;
+                z.h_max = std::max(z.h_max, z.comp[i].h); z.v_max = std::max(z.v_max, z.comp[i].v);
+            }
+            for (int i = 0; i < z.ncomp; i++)
+                if (z.h_max % z.comp[i].h != 0 || z.v_max % z.comp[i].v != 0) return false;
+            z.mcu_x = (z.w + z.h_max * 8 - 1) / (z.h_max * 8);
+            z.mcu_y = (z.h + z.v_max * 8 - 1) / (z.v_max * 8);
+            for (int i = 0; i < z.ncomp; i++)
+            {
+                JpegComp& c = z.comp[i];
+                c.x = (z.w * c.h + z.h_max - 1) / z.h_max;
+                c.y = (z.h * c.v + z.v_max - 1) / z.v_max;
+                c.w2 = z.mcu_x * c.h * 8; c.h2 = z.mcu_y * c.v * 8;
+                c.data.assign((size_t)c.w2 * c.h2, 0);
+            }
+            have_frame = true;
+        }
+        else if (m == 0xc2) return false;                          // progressive: unsupported
+        else if (m == 0xc4)                                        // DHT
+        {
+            int L = z.get16() - 2;
+            while (L > 0)
+            {
+                int q = z.get8(); int tc = q >> 4, th = q & 15;
+                if (tc > 1 || th > 3) return false;
+                int count[16], n = 0;
+                for (int i = 0; i < 16; i++) { count[i] = z.get8(); n += count[i]; }
+                if (n > 256) return false;
+                L -= 17;
+                JpegHuff& hf = tc == 0 ? z.hdc[th] : z.hac[th];
+                if (!hf.build(count)) return false;
+                for (int i = 0; i < n; i++) hf.values[i] = (unsigned char)z.get8();
+                L -= n;
+            }
+        }
+        else if (m == 0xdb)                                        // DQT
+        {
+            int L = z.get16() - 2;
+            while (L > 0)
+            {
+                int q = z.get8(); int p16 = q >> 4, t = q & 15;
+                if (t > 3 || p16 > 1) return false;
+                for (int i = 0; i < 64; i++) z.dequant[t][kJpegDezigzag[i]] = (unsigned short)(p16 ? z.get16() : z.get8());
+                L -= p16 ? 129 : 65;
+            }
+        }
+        else if (m == 0xdd) { if (z.get16() != 4) return false; z.restart_interval = z.get16(); }
+        else if (m == 0xda)                                        // SOS
+        {
+            if (!have_frame) return false;
+            int Ls = z.get16();
+            z.scan_n = z.get8();
+            if (z.scan_n < 1 || z.scan_n > z.ncomp || Ls != 6 + 2 * z.scan_n) return false;
+            for (int i = 0; i < z.scan_n; i++)
+            {
+                int id = z.get8(), q = z.get8(), which;
+                for (which = 0; which < z.ncomp; which++) if (z.comp[which].id == id) break;
+                if (which == z.ncomp) return false;
+                z.comp[which].hd = q >> 4; z.comp[which].ha = q & 15;
+                if (z.comp[which].hd > 3 || z.comp[which].ha > 3) return false;
+                z.order[i] = which;
+            }
+            z.get8(); z.get8(); z.get8();                          // Ss, Se, Ah/Al (baseline: 0, 63, 0)
+            if (!jpeg_scan(z)) return false;
+            decoded = true;
+            if (z.marker == 0xff)
+            {
+                // skip entropy-coded bytes that a scan left unread, up to the next marker
+                while (z.p < z.end)
+                {
+                    int x = z.get8();
+                    if (x == 0xff) { int y = z.get8(); if (y != 0 && y != 0xff) { z.marker = y; break; } if (y == 0xff && z.p < z.end) z.p--; }
+                }
+            }
+        }
+        else if (m == 0xe0)                                        // APP0: JFIF
+        {
+            int L = z.get16();
+            if (L < 2) return false;
+            L -= 2;
+            if (L >= 5)
+            {
+                static const unsigned char tag[5] = { 'J', 'F', 'I', 'F', 0 };
+                int ok = 1;
+                for (int i = 0; i < 5; i++) if (z.get8() != tag[i]) ok = 0;
+                L -= 5;
+                if (ok) z.jfif = 1;
+            }
+            z.p += std::min<long>(L, z.end - z.p);
+        }
+        else if (m == 0xee)                                        // APP14: Adobe
+        {
+            int L = z.get16();
+            if (L < 2) return false;
+            L -= 2;
+            if (L >= 12)
+            {
+                static const unsigned char tag[6] = { 'A', 'd', 'o', 'b', 'e', 0 };
+                int ok = 1;
+                for (int i = 0; i < 6; i++) if (z.get8() != tag[i]) ok = 0;
+                L -= 6;
+                if (ok) { z.get8(); z.get16(); z.get16(); z.app14 = z.get8(); L -= 6; }
+            }
+            z.p += std::min<long>(L, z.end - z.p);
+        }
+        else if ((m >= 0xe0 && m <= 0xef) || m == 0xfe || (m >= 0xc5 && m <= 0xcf && m != 0xc8))
+        {
+            int L = z.get16();
+            if (L < 2) return false;
+            z.p += std::min<long>(L - 2, z.end - z.p);
+        }
+        else if (m == 0xff) { /* fill bytes */ }
+        else return false;
+        m = next_marker();
+    }
+    if (!decoded) return false;
+
+    // resample + colour convert, forced to 4 channels (stbi_load(..., 4))
+    w = z.w; h = z.h;
+    const bool is_rgb = z.ncomp == 3 && (z.rgb == 3 || (z.app14 == 0 && !z.jfif));
+    rgba.resize((size_t)w * h * 4);
+    struct Res { int hs, vs, ystep, w_lores, ypos; const unsigned char *line0, *line1; std::vector<unsigned char> buf;
+                 const unsigned char* (*fn)(unsigned char*, const unsigned char*, const unsigned char*, int, int); } res[3];
+    for (int k = 0; k < z.ncomp; k++)
+    {
+        Res& r = res[k];
+        r.hs = z.h_max / z.comp[k].h; r.vs = z.v_max / z.comp[k].v;
+        r.ystep = r.vs >> 1; r.w_lores = (w + r.hs - 1) / r.hs; r.ypos = 0;
+        r.line0 = r.line1 = z.comp[k].data.data();
+        r.buf.resize((size_t)w + 3 + 8);
+        r.fn = (r.hs == 1 && r.vs == 1) ? jres_1 : (r.hs == 1 && r.vs == 2) ? jres_v2 : (r.hs == 2 && r.vs == 1) ? jres_h2
+             : (r.hs == 2 && r.vs == 2) ? jres_hv2 : jres_generic;
+    }
+    const unsigned char* co[3] = { 0, 0, 0 };
+    for (int j = 0; j < h; j++)
+    {
+        unsigned char* out = &rgba[(size_t)j * w * 4];
+        for (int k = 0; k < z.ncomp; k++)
+        {
+            Res& r = res[k];
+            int y_bot = r.ystep >= (r.vs >> 1);
+            co[k] = r.fn(r.buf.data(), y_bot ? r.line1 : r.line0, y_bot ? r.line0 : r.line1, r.w_lores, r.hs);
+            if (++r.ystep >= r.vs)
+            {
+                r.ystep = 0;
+                r.line0 = r.line1;
+                if (++r.ypos < z.comp[k].y) r.line1 += z.comp[k].w2;
+            }
+        }
+        if (z.ncomp == 3 && !is_rgb)
+        {
+            for (int i = 0; i < w; i++)                            // stbi__YCbCr_to_RGB_row
+            {
+                int y_fixed = (co[0][i] << 20) + (1 << 19);
+                int cr = co[2][i] - 128, cb = co[1][i] - 128;
+                const int f1402 = ((int)(1.40200f * 4096.0f + 0.5f)) << 8, f0714 = ((int)(0.71414f * 4096.0f + 0.5f)) << 8;
+                const int f0344 = ((int)(0.34414f * 4096.0f + 0.5f)) << 8, f1772 = ((int)(1.77200f * 4096.0f + 0.5f)) << 8;
+                int r = y_fixed + cr * f1402;
+                int g = y_fixed + (cr * -f0714) + ((cb * -f0344) & 0xffff0000);
+                int b = y_fixed + cb * f1772;
+                r >>= 20; g >>= 20; b >>= 20;
+                out[0] = jclamp(r); out[1] = jclamp(g); out[2] = jclamp(b); out[3] = 255;
+                out += 4;
+            }
+        }
+        else if (z.ncomp == 3)
+            for (int i = 0; i < w; i++) { out[0] = co[0][i]; out[1] = co[1][i]; out[2] = co[2][i]; out[3] = 255; out += 4; }
+        else
+            for (int i = 0; i < w; i++) { out[0] = out[1] = out[2] = co[0][i]; out[3] = 255; out += 4; }
+    }
+    return true;
+}
+
 void downscale_area(const std::vector<unsigned char>& src, int w, int h, int nw, int nh, std::vector<unsigned char>& dst)
 {
     dst.resize((size_t)nw * nh * 4);
@@ -239,7 +736,7 @@ void Image::Load(const std::string& filename)
     std::vector<unsigned char> file, rgba;
     int w = 0, h = 0;
     if (!read_file(filename, file)) return;                       // missing file -> mData == 0 -> sampler returns 0
-    if (!decode_pnm(file, w, h, rgba) && !decode_png(file, w, h, rgba)) return;
+    if (!decode_pnm(file, w, h, rgba) && !decode_png(file, w, h, rgba) && !decode_jpeg(file, w, h, rgba)) return;
     if (w > 1024 || h > 1024)
     {
         float scale = 1024.f / fmax(w, h);                        // image.cpp:49

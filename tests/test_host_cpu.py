@@ -233,3 +233,20 @@ def test_png_export_flips_to_top_down(tmp_path):
     assert P.export_png(p, img)
     back = P.image_load(p)                                         # our decoder reads it back top-down
     assert np.array_equal(back[..., :3], img[::-1]) and (back[..., 3] == 255).all()
+
+
+def test_texture_decoders_match_stb_image(tmp_path):
+    """Image::Load (image.cpp:38-61) = stbi_load(file, ..., 4): JPEG (baseline, 4:4:4 / 4:2:2 / 4:2:0, grey,
+    restart markers, odd sizes) and PNG (RGB, RGBA, grey, grey+alpha, palette, 16-bit, 1-bit) files decode to
+    the very RGBA8 texels the reference's stb_image 2.27 produces (golden: oracle/gen_golden.py)."""
+    from pbrpathtracer_amd import pathtracer as P
+    z = load_golden("tier_k_images.npz")
+    assert len(z["names"]) >= 16
+    for name in z["names"]:
+        name = str(name)
+        p = str(tmp_path / (name + (".jpg" if name.startswith("jpg") else ".png")))
+        open(p, "wb").write(z["file_" + name].tobytes())
+        got = P.image_load(p)
+        assert got is not None, name
+        assert got.shape == z["rgba_" + name].shape, name
+        assert np.array_equal(got, z["rgba_" + name]), (name, int(np.abs(got.astype(int) - z["rgba_" + name].astype(int)).max()))
