@@ -360,7 +360,7 @@ __device__ __forceinline__ uint32_t pixel_key(uint32_t seed_lo, uint32_t seed_hi
     return hash32(pixel + b);
 }
 
-enum : int { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_DONE = 3 };
+enum : int { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_DONE = 3, ST_NEED = 4 };
 
 // FLAT = the scene has so few triangles (P.flat_count <= 16) that no hierarchy is walked: a traversing
 // lane tests every triangle, the records are fetched with SCALAR loads (one s_load per triangle per
@@ -388,18 +388,39 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     const bool valid = px < P.width && py < P.height;
     const uint32_t s_begin = (uint32_t)chunk_id * (uint32_t)P.chunk;
     const uint32_t s_count = min((uint32_t)P.chunk, P.spp - s_begin);  // host guarantees s_begin < spp
-    const size_t out_base = ((size_t)item * P.chunk) * 64 + lane;      // sample s of this lane: P.samples[out_base + s * 64]
+    const size_t out_base = ((size_t)item * P.chunk) * 64;             // sample s of tile pixel q: P.samples[out_base + s * 64 + q]
 
-    const uint32_t pix = valid ? (uint32_t)(py * P.width + px) : 0u;    // row-major from the top
-    const uint32_t pkey = valid ? pixel_key(P.seed_lo, P.seed_hi, pix) : 0u;
+    // Work units of this item = (live pixel of the 8x8 tile, sample of the chunk), sample-major.  They are
+    // dealt to whichever lane needs work next, NOT pinned pixel-to-lane: every lane of the wave keeps
+    // tracing until the item's units are used up, so lanes finish within one path of each other
+    // (a pixel-per-lane mapping idles the wave while its unluckiest pixel finishes its 16-32 samples,
+    // and idles the lanes of off-image or sky pixels altogether).
+    __shared__ unsigned char lds_pixel_of_rank[PTK_TRACE_BLOCK];
+    // a pixel whose cached primary ray misses is black for every sample (pathtracer.cpp:550): nothing is
+    // traced or stored for it, and accumulate_kernel skips its (all-zero) samples
+    const bool black = P.primary_hit && valid && __float_as_int(P.primary_hit[(size_t)py * P.width + px].x) == PTK_NOHIT;
+    const bool live_pixel = valid && !black && s_count > 0;
+    const unsigned long long live_mask = __ballot(live_pixel);
+    const uint32_t n_live_px = (uint32_t)__popcll(live_mask);
+    if (n_live_px == 0)
+    {
+        if (STATS) atomicAdd(&P.stats[0], (unsigned long long)(valid ? s_count : 0));
+        return;                     // whole wave; the workgroup is this one wave
+    }
+    const uint32_t total_units = n_live_px * s_count;
+    if (live_pixel) lds_pixel_of_rank[(tid & ~63) + __popcll(live_mask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+    __syncthreads();
+    uint32_t next_unit = 0;         // wave-uniform
+    int q = 0;                      // tile pixel (0..63) of the path this lane is tracing
+    uint32_t pix = 0;               // its row-major pixel index from the top
+
     const v3 camPos0 = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
     const v3 camRight = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
     const v3 camUp = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
 
     Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Rng rng;
-    rng.inc = (hash32(pkey ^ 0x9E3779B9u) << 1) | 1u;
-    rng.state = 0; rng.key = 0;
+    rng.inc = 1u; rng.state = 0; rng.key = 0;
 
     // per-lane path state
     Walk W;
@@ -414,20 +435,13 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     bool inside = false;
     uint32_t ray = 0;
     uint32_t sample = 0;            // index inside this chunk
-    int st = (valid && s_count > 0) ? ST_GEN : ST_DONE;
-    if (P.primary_hit && valid)
-    {
-        // a pixel whose primary ray misses is black for every sample (pathtracer.cpp:550): nothing is
-        // traced or stored, and accumulate_kernel skips its (all-zero) samples
-        if (__float_as_int(P.primary_hit[pix].x) == PTK_NOHIT) st = ST_DONE;
-    }
+    int st = ST_NEED;               // every lane works, whatever its own pixel is
 
     // a finished path: its radiance goes to the sample buffer, the lane moves to its next sample
 #define PTK_FINISH_PATH()                                                                         \
     do {                                                                                          \
-        P.samples[out_base + (size_t)sample * 64] = make_float4(L.x, L.y, L.z, 0.0f);              \
-        sample++;                                                                                 \
-        st = sample < s_count ? ST_GEN : ST_DONE;                                                 \
+        P.samples[out_base + (size_t)sample * 64 + q] = make_float4(L.x, L.y, L.z, 0.0f);          \
+        st = ST_NEED;                                                                             \
     } while (0)
 
     // a finished walk: shadow rays resolve DirectIllumimation's visibility and roll into the sampled
@@ -452,6 +466,28 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     int debt_shade = 0, debt_gen = 0;      // wave-uniform: lane-iterations wasted by parked lanes
     for (;;)
     {
+        {
+            // deal the next work units to the lanes that need one (wave-uniform code)
+            const unsigned long long m_need = __ballot(st == ST_NEED);
+            if (m_need)
+            {
+                if (st == ST_NEED)
+                {
+                    const uint32_t u = next_unit + (uint32_t)__popcll(m_need & ((1ull << lane) - 1ull));
+                    if (u < total_units)
+                    {
+                        sample = u / n_live_px;
+                        q = lds_pixel_of_rank[(tid & ~63) + (u - sample * n_live_px)];
+                        const int qx = tx * PTK_TILE + (quad & 1) * 8 + (q & 7);
+                        const int qy = ty * PTK_TILE + (quad >> 1) * 8 + (q >> 3);   // row from the top (pathtracer.cpp:777)
+                        pix = (uint32_t)(qy * P.width + qx);
+                        st = ST_GEN;
+                    }
+                    else st = ST_DONE;
+                }
+                next_unit += (uint32_t)__popcll(m_need);
+            }
+        }
         const unsigned long long m_trav = __ballot(st == ST_TRAV);
         const unsigned long long m_shade = __ballot(st == ST_SHADE);
         const unsigned long long m_gen = __ballot(st == ST_GEN);
@@ -746,6 +782,8 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
             if (st == ST_GEN)
             {
                 // ---- camera ray with thin-lens DOF, pathtracer.cpp:785-791 + SampleCircle :734-739 ----
+                const uint32_t pkey = pixel_key(P.seed_lo, P.seed_hi, pix);
+                rng.inc = (hash32(pkey ^ 0x9E3779B9u) << 1) | 1u;
                 rng.state = hash32(P.first_sample + s_begin + sample + pkey);
                 rng.key = rng.state;
                 // per-pixel constants are re-read here (L1/L2 hits) instead of living in registers
