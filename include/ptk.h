@@ -86,6 +86,7 @@ typedef struct ptk_stats {
     uint64_t walk_wave_iters, walk_lane_iters;     /* BVH-walk loop iterations per wave, and lanes active in them */
     uint64_t shade_wave_execs, shade_lanes;        /* shading block executions per wave, lanes shaded */
     uint64_t gen_wave_execs, gen_lanes;            /* camera-ray block executions per wave, lanes generated */
+    uint64_t tri_wave_execs, tri_lanes;            /* triangle-arm executions of the BVH walk per wave, lanes testing */
 } ptk_stats;
 
 typedef struct ptk_ctx ptk_ctx;
@@ -152,7 +153,9 @@ int ptk_gather_accum(ptk_ctx* ctx, void* rccl_comm, int root);
  * budget of the sample buffer between the trace and accumulate kernels (default 4 GiB);
  * "shade_threshold" / "gen_threshold" = scheduling lambdas of the wave state machine in eighths
  * (cost of the shading / camera-ray block relative to one BVH walk step; defaults: shading 200 for
- * trees of depth <= 8 else 40 (0 = this automatic choice), camera rays 16); "primary_cache" = 0/1, reuse the camera ray's closest
+ * trees of depth <= 8 else 40 (0 = this automatic choice), camera rays 16); "tri_threshold" = the
+ * triangle arm of the BVH walk runs once the lanes holding a leaf reach this many eighths of the lanes
+ * that can still walk (default 4; 0 = every iteration); "primary_cache" = 0/1, reuse the camera ray's closest
  * hit across samples when the camera is a pinhole and the scene has no opacity texture (default 1). */
 int ptk_set_option(ptk_ctx* ctx, const char* name, double value);
 

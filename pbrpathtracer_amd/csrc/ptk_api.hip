@@ -62,6 +62,7 @@ struct ptk_ctx {
     float4* d_samples = nullptr;
     size_t samples_bytes = 0;
     int opt_chunk = 0;                           // samples per work item; 0 = automatic (16, or 32 in FLAT mode)
+    int opt_tri_thr = 4;                         // triangle arm of the walk runs when queued lanes >= tri_thr/8 x walking lanes
     int opt_shade_thr = 0, opt_gen_thr = 16;     // scheduling lambdas in eighths, see trace_kernel; 0 = by tree depth
     size_t opt_pass_bytes = (size_t)4 << 30;     // sample-buffer budget per pass
 
@@ -154,6 +155,7 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     // wave (lambda 25); deep trees have heavy-tailed walks: shade small batches early (lambda 5)
     p.shade_thr = c->opt_shade_thr > 0 ? c->opt_shade_thr : (c->bvh_depth <= 8 ? 200 : 40);
     p.gen_thr = c->opt_gen_thr;
+    p.tri_thr = c->opt_tri_thr;
     p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.stats = c->d_stats;
     p.num_nodes = c->num_nodes; p.num_lights = c->num_lights;
     p.flat_count = (c->opt_flat && c->num_tris <= 16) ? c->num_tris : 0;
@@ -578,6 +580,7 @@ int ptk_collect_stats(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uin
     out->tri_tests = h[4]; out->hits_shaded = h[5]; out->tex_fetches = h[6];
     out->walk_wave_iters = h[7]; out->walk_lane_iters = h[8]; out->shade_wave_execs = h[9]; out->shade_lanes = h[10];
     out->gen_wave_execs = h[11]; out->gen_lanes = h[12];
+    out->tri_wave_execs = h[13]; out->tri_lanes = h[14];
     return PTK_OK;
 }
 
@@ -712,6 +715,12 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     {
         if (!(value >= 0 && value <= 4096)) return fail(c, PTK_ERR_BAD_ARG, "threshold (lambda in eighths) must be in [0, 4096]");
         (name[0] == 's' ? c->opt_shade_thr : c->opt_gen_thr) = (int)value;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "tri_threshold"))
+    {
+        if (!(value >= 0 && value <= 4096)) return fail(c, PTK_ERR_BAD_ARG, "tri_threshold (eighths) must be in [0, 4096]");
+        c->opt_tri_thr = (int)value;
         return PTK_OK;
     }
     if (!std::strcmp(name, "flat_shade_weight") || !std::strcmp(name, "flat_gen_weight"))

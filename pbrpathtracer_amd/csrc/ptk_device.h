@@ -49,6 +49,7 @@ struct RenderParams {
     int chunk, num_chunks;      // samples per work item, work items per 8x8 tile
     int num_items;              // owned tiles * 4 * num_chunks
     int shade_thr, gen_thr;     // scheduling lambdas (eighths): cost of the shade / gen block in walk steps
+    int tri_thr;                // triangle arm runs when lanes with a queued triangle >= tri_thr/8 x lanes with a node
     const float4* nodes;
     const float4* tris;
     const float4* shade;

@@ -158,7 +158,7 @@ __device__ __forceinline__ float tex2d_r(const PT& P, int tex, float uvx, float 
 
 struct Hit { int tri; float t, u, v; };
 
-struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex, walk_iters, walk_lanes, shade_execs, shade_lanes, gen_execs, gen_lanes; };
+struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex, walk_iters, walk_lanes, shade_execs, shade_lanes, gen_execs, gen_lanes, tri_execs, tri_lanes; };
 
 // ---- closest hit (replaces the recursive PathTracer::Hit, pathtracer.cpp:411-492) ---------------------
 // The walk is re-entrant: all of its state lives in this struct so a wave can interleave BVH steps
@@ -291,9 +291,10 @@ __device__ __forceinline__ bool tri_test(const PT& P, Walk& W, float4 t0, float4
 // (the wave executes both arms every iteration anyway).  The price is slightly later t-max tightening;
 // the result is unaffected (closest hit is order-independent).
 template <bool STATS, int STRIDE, class PT>
-__device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, uint32_t ray, int* stack, Counters& cnt)
+__device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, uint32_t ray, int* stack, Counters& cnt,
+                                          const bool run_tri_arm = true)
 {
-    if (W.tri_left > 0)                                   // ---- arm A: one triangle
+    if (run_tri_arm && W.tri_left > 0)                    // ---- arm A: one triangle
     {
         const float4* tp = P.tris + (size_t)W.tri_next * TRI_F4;
         float4 t0 = ldg4(tp), t1 = ldg4(tp + 1), t2 = ldg4(tp + 2);
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     const v3 camRight = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
     const v3 camUp = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Rng rng;
     rng.inc = 1u; rng.state = 0; rng.key = 0;
 
@@ -552,9 +553,21 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
             do
             {
                 if (STATS) { const uint32_t nt = (uint32_t)__popcll(__ballot(st == ST_TRAV)); if (lane == 0) { cnt.walk_iters++; cnt.walk_lanes += nt; } }
+                // arm A (triangles) is voted: about one triangle is tested per four nodes visited, so run
+                // every iteration it would execute with ~1/7 of the lanes.  A lane parks its leaf and walks
+                // on until it reaches the next leaf; the arm runs once enough lanes wait for it (P.tri_thr
+                // eighths of the lanes that still have a node to visit) or nobody can walk on.  Deferring
+                // only delays t-max tightening: the closest hit is order-independent.  (Measured: waiting
+                // for half of the walking lanes, thr 4, is the optimum - beyond that the rays whose walk
+                // is finished but for the parked leaf idle too long; a 4-deep leaf ring per lane made
+                // that worse, not better.)
+                const int n_tq = __popcll(__ballot(st == ST_TRAV && W.tri_left > 0));
+                const int n_nr = __popcll(__ballot(st == ST_TRAV && W.node >= 0));
+                const bool run_tri_arm = n_tq > 0 && (n_nr == 0 || n_tq * 8 >= P.tri_thr * n_nr);
+                if (STATS && lane == 0 && run_tri_arm) { cnt.tri_execs++; cnt.tri_lanes += (uint32_t)n_tq; }
                 if (st == ST_TRAV)
                 {
-                    walk_step<STATS, PTK_TRACE_BLOCK>(P, W, rng, ray, stack, cnt);
+                    walk_step<STATS, PTK_TRACE_BLOCK>(P, W, rng, ray, stack, cnt, run_tri_arm);
                     if (W.done()) PTK_WALK_DONE();
                 }
                 const int nt = __popcll(__ballot(st == ST_TRAV));
@@ -840,6 +853,8 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
             atomicAdd(&P.stats[10], (unsigned long long)cnt.shade_lanes);
             atomicAdd(&P.stats[11], (unsigned long long)cnt.gen_execs);
             atomicAdd(&P.stats[12], (unsigned long long)cnt.gen_lanes);
+            atomicAdd(&P.stats[13], (unsigned long long)cnt.tri_execs);
+            atomicAdd(&P.stats[14], (unsigned long long)cnt.tri_lanes);
         }
     }
 }
@@ -916,7 +931,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void primary_hits_kernel(const RenderPar
     const int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (i >= P.width * P.height) return;
     Rng rng; rng.inc = 1u; rng.state = 0u; rng.key = 0u;            // no opacity draws can occur here
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     float4 d = P.primary[i];
     const v3 camPos0 = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
     v3 focalPoint = add(camPos0, muls(V(d.x, d.y, d.z), P.focal_dist));
@@ -935,7 +950,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_hits_kernel(const ProbeParams
     int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (i >= P.n) return;
     Rng rng; rng.inc = (hash32(0u ^ 0x9E3779B9u) << 1) | 1u; rng.state = hash32(0u); rng.key = rng.state;
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     v3 ro = V(P.ro[i * 3], P.ro[i * 3 + 1], P.ro[i * 3 + 2]);
     v3 rd = V(P.rd[i * 3], P.rd[i * 3 + 1], P.rd[i * 3 + 2]);
     Walk W;

@@ -42,7 +42,8 @@ class SceneDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
                 ("samples", "rays", "shadow_rays", "node_visits", "tri_tests", "hits_shaded", "tex_fetches",
-                 "walk_wave_iters", "walk_lane_iters", "shade_wave_execs", "shade_lanes", "gen_wave_execs", "gen_lanes")]
+                 "walk_wave_iters", "walk_lane_iters", "shade_wave_execs", "shade_lanes", "gen_wave_execs", "gen_lanes",
+                 "tri_wave_execs", "tri_lanes")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
