@@ -377,7 +377,16 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     int* stack = lds_stack + tid;
     const int lane = tid & 63;
     // work item of this WAVE: (owned 16x16 tile, 8x8 quadrant, chunk of samples)
-    const int item = blockIdx.x * (PTK_TRACE_BLOCK / 64) + (tid >> 6);
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each
+    // with its own L2.  Hand every XCD whole 16x16 tiles (run = the 4 x num_chunks work items of a tile), tile
+    // by tile round-robin, so the waves that trace the same pixels - the same BVH nodes and triangles - share
+    // an L2 instead of being sprayed over all eight.  (Runs, not one contiguous eighth of the frame per XCD:
+    // the dispatcher deals blocks in order, so an XCD holding the cheap part of the image would stall the rest.)
+    static_assert(PTK_TRACE_BLOCK == 64, "the XCD mapping below assumes one wave per workgroup");
+    const int run = 4 * P.num_chunks;
+    const int b = (int)blockIdx.x;
+    const int slot = b >> 3;                                           // b-th wave dealt to XCD (b & 7)
+    const int item = ((slot / run) * 8 + (b & 7)) * run + slot % run;
     const int subtile = item / P.num_chunks, chunk_id = item - subtile * P.num_chunks;
     const int owned = subtile >> 2, quad = subtile & 3;
     const int tile = owned * P.world + P.rank;
@@ -966,6 +975,9 @@ void launch_trace(const RenderParams& p, int num_items, hipStream_t stream, bool
 {
     if (num_items <= 0) return;
     int blocks = (num_items + (PTK_TRACE_BLOCK / 64) - 1) / (PTK_TRACE_BLOCK / 64);
+    // trace_kernel deals whole tiles (runs of 4 * num_chunks items) to the 8 XCDs: pad to 8 runs
+    const int group = 8 * 4 * p.num_chunks;
+    blocks = (num_items + group - 1) / group * group / (PTK_TRACE_BLOCK / 64);
     const bool flat = p.flat_count > 0;
     if (stats && flat) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
     else if (stats) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
