@@ -352,11 +352,35 @@ def tier_k_images(ref: Ref, tmp: str):
     save("tier_k_images.npz", names=np.array(names), **out)
 
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+from resize_cases import RESIZE_CASES, resize_case_input   # noqa: E402  (shared with tests/test_host_cpu.py)
+
+
+def tier_k_resize(ref: Ref, tmp: str):
+    """Image::Load on files with a side > 1024 (image.cpp:47-60): stbir_resize_uint8 of stb_image_resize
+    v0.97, default (Mitchell) downsampling.  Inputs are regenerated from resize_case_input() by the test;
+    the expected reduced RGBA8 comes from the reference."""
+    from PIL import Image as PI
+    out = {}
+    for name in RESIZE_CASES:
+        a = resize_case_input(name)
+        p = os.path.join(tmp, name + ".png")
+        PI.fromarray(a, {2: "L", 3: "RGB" if a.ndim == 3 and a.shape[2] == 3 else "RGBA"}[a.ndim if a.ndim == 2 else 3]).save(p, "PNG")
+        w = C.c_int(); h = C.c_int()
+        assert ref.lib.ref_image_load(p.encode(), C.byref(w), C.byref(h)) == 1, name
+        px = np.zeros((h.value, w.value, 4), np.uint8)
+        ref.lib.ref_image_data(px.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        out["rgba_" + name] = px
+        print("  resize", name, a.shape, "->", px.shape)
+    save("tier_k_resize.npz", names=np.array(RESIZE_CASES), **out)
+
+
 def main():
     ref = Ref()
     with tempfile.TemporaryDirectory() as tmp:
         tier_k(ref, tmp)
         tier_k_images(ref, tmp)
+        tier_k_resize(ref, tmp)
         tier_k_scene(ref, tmp)
         tier_t(ref, tmp)
         tier_s(ref, tmp)

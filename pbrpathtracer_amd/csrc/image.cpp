@@ -5,9 +5,8 @@
 // Formats: binary PNM (P5 / P6, maxval <= 255 or 16-bit), non-interlaced PNG (colour types 0, 2, 3, 4, 6;
 // bit depths 1-16) through zlib, and baseline / extended-sequential Huffman JPEG (grey, YCbCr, RGB).  Everything is expanded to 4 channels the way stbi_load(..., 4)
 // does (grey -> g,g,g,255; 16-bit -> high byte).  Images with a side > 1024 are reduced so the
-// longest side is 1024 (image.cpp:47-60) — with an area-average filter, not stb_image_resize's
-// Mitchell kernel: the resulting SIZE is pinned by the golden vectors, the filtered texel values are
-// "parity unpinned".
+// longest side is 1024 (image.cpp:47-60) with stb_image_resize's default downsampling (Mitchell kernel,
+// clamped edges), bit-identically (tests/golden/tier_k_resize.npz).
 #include <zlib.h>
 
 #include <algorithm>
@@ -675,30 +674,140 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
     return true;
 }
 
-void downscale_area(const std::vector<unsigned char>& src, int w, int h, int nw, int nh, std::vector<unsigned char>& dst)
+// ---- reduction of images with a side > 1024 (image.cpp:47-60) ---------------------------------------
+// The reference calls stbir_resize_uint8(src, w, h, 0, dst, nw, nh, 0, 4) of stb_image_resize v0.97
+// (include/stb_image_resize.h:2462-2470): linear colour space, no alpha weighting, clamped edges and the
+// default downsampling filter, Mitchell-Netravali (B = C = 1/3).  Its "downsample" path is a SCATTER: per
+// axis, every input pixel (plus a margin of clamped virtual pixels) owns up to four weights towards the
+// output pixels whose footprint it falls in; the weights are then normalised per OUTPUT pixel.  The
+// restatement below keeps that structure and the float evaluation order (sums run over ascending input
+// index; rows: horizontal pass first, then the vertical scatter), so the texels come out bit-identical
+// (tests/golden/tier_k_resize.npz, produced by the reference itself).
+struct AxisWeights {
+    int margin = 0;                   // virtual input pixels on either side of the image
+    std::vector<int> first, last;     // per input pixel (index + margin): output pixels it feeds, inclusive
+    std::vector<float> w;             // 4 weights per input pixel, for first .. first + 3
+};
+
+float mitchell(float x)               // stb_image_resize.h:825-837
 {
-    dst.resize((size_t)nw * nh * 4);
-    for (int y = 0; y < nh; y++)
+    x = std::fabs(x);
+    if (x < 1.0f) return (16 + x * x * (21 * x - 36)) / 18;
+    if (x < 2.0f) return (32 + x * (-60 + x * (36 - 7 * x))) / 18;
+    return 0.0f;
+}
+
+// output pixels reached by input pixel n (stb_image_resize.h:1024-1036); also gives the input pixel's
+// centre in output space
+void footprint(int n, float radius_in, float scale, int* first, int* last, float* centre_out)
+{
+    const float c = (float)n + 0.5f;
+    const float lo = (c - radius_in) * scale - 0.0f, hi = (c + radius_in) * scale - 0.0f;
+    *centre_out = c * scale - 0.0f;
+    *first = (int)std::floor(lo + 0.5);                 // double arithmetic, as there
+    *last = (int)std::floor(hi - 0.5);
+}
+
+void build_axis(int in_size, int out_size, AxisWeights& A)
+{
+    const float scale = (float)out_size / in_size;                       // :2229-2230 with s0,t0 = 0 and s1,t1 = 1
+    const float support = 2.0f;
+    A.margin = (int)std::ceil(support * 2 / scale) / 2;                   // :883-899
+    const int num = in_size + A.margin * 2;                              // :909-915
+    const float radius_in = support / scale;                             // :1224
+    A.first.assign(num, 0); A.last.assign(num, 0);
+    A.w.assign((size_t)num * 4 + 8, 0.0f);                               // slack: a footprint of five spills into the next group, as there
+    for (int n = 0; n < num; n++)                                        // :1227-1237, :1092-1124
     {
-        double y0 = (double)y * h / nh, y1 = (double)(y + 1) * h / nh;
-        for (int x = 0; x < nw; x++)
+        int f, l; float centre;
+        footprint(n - A.margin, radius_in, scale, &f, &l, &centre);
+        float* g = &A.w[(size_t)n * 4];
+        A.first[n] = f; A.last[n] = l;
+        for (int i = 0; i <= l - f && i < 8; i++)
+            g[i] = mitchell(((float)(i + f) + 0.5f) - centre) * scale;
+        for (int i = std::min(l - f, 7); i >= 0; i--)                    // trailing zero weights drop out
         {
-            double x0 = (double)x * w / nw, x1 = (double)(x + 1) * w / nw;
-            double acc[4] = { 0, 0, 0, 0 }, wsum = 0;
-            for (int sy = (int)y0; sy < h && sy < y1; sy++)
-            {
-                double wy = std::min(y1, (double)sy + 1) - std::max(y0, (double)sy);
-                for (int sx = (int)x0; sx < w && sx < x1; sx++)
-                {
-                    double wx = std::min(x1, (double)sx + 1) - std::max(x0, (double)sx);
-                    const unsigned char* p = &src[((size_t)sy * w + sx) * 4];
-                    double ww = wx * wy;
-                    for (int k = 0; k < 4; k++) acc[k] += ww * p[k];
-                    wsum += ww;
-                }
-            }
-            for (int k = 0; k < 4; k++) dst[((size_t)y * nw + x) * 4 + k] = (unsigned char)std::lround(acc[k] / (wsum > 0 ? wsum : 1));
+            if (g[i]) break;
+            A.last[n] = f + i - 1;
         }
+    }
+    // normalise per output pixel (:1126-1158)
+    for (int i = 0; i < out_size; i++)
+    {
+        float total = 0;
+        for (int j = 0; j < num; j++)
+        {
+            if (i >= A.first[j] && i <= A.last[j]) total += A.w[(size_t)j * 4 + (i - A.first[j])];
+            else if (i < A.first[j]) break;
+        }
+        const float s = 1 / total;
+        for (int j = 0; j < num; j++)
+        {
+            if (i >= A.first[j] && i <= A.last[j]) A.w[(size_t)j * 4 + (i - A.first[j])] *= s;
+            else if (i < A.first[j]) break;
+        }
+    }
+    // leading zero weights and output pixels outside the image drop out (:1160-1193)
+    for (int j = 0; j < num; j++)
+    {
+        float* g = &A.w[(size_t)j * 4];
+        int skip = 0;
+        while ((size_t)j * 4 + skip < A.w.size() - 1 && g[skip] == 0) skip++;
+        A.first[j] += skip;
+        while (A.first[j] < 0) { A.first[j]++; skip++; }
+        const int range = A.last[j] - A.first[j] + 1;
+        const int mx = std::min(4, range);
+        for (int i = 0; i < mx; i++)
+        {
+            if (i + skip >= 4) break;
+            g[i] = g[i + skip];
+        }
+    }
+    for (int j = 0; j < num; j++) A.last[j] = std::min(A.last[j], out_size - 1);
+}
+
+void downscale_mitchell(const std::vector<unsigned char>& src, int w, int h, int nw, int nh, std::vector<unsigned char>& dst)
+{
+    AxisWeights H, V;
+    build_axis(w, nw, H);
+    build_axis(h, nh, V);
+    const float vscale = (float)nh / h, vradius = 2.0f / vscale;
+    std::vector<float> acc((size_t)nw * nh * 4, 0.0f), row((size_t)nw * 4);
+    for (int y = -V.margin; y < h + V.margin; y++)                        // :2165-2203
+    {
+        int f, l; float centre;
+        footprint(y, vradius, vscale, &f, &l, &centre);
+        if (l < 0 || f >= nh) continue;
+        // horizontal pass of input row y (clamped) into `row` (:1252-1290, :1533-1650)
+        std::fill(row.begin(), row.end(), 0.0f);
+        const unsigned char* in = &src[(size_t)std::min(std::max(y, 0), h - 1) * w * 4];
+        for (int x = 0; x < w + H.margin * 2; x++)
+        {
+            const unsigned char* p = in + (size_t)std::min(std::max(x - H.margin, 0), w - 1) * 4;
+            const float d0 = (float)p[0] / 255.0f, d1 = (float)p[1] / 255.0f, d2 = (float)p[2] / 255.0f, d3 = (float)p[3] / 255.0f;
+            const float* g = &H.w[(size_t)x * 4];
+            for (int k = H.first[x]; k <= H.last[x]; k++)
+            {
+                const float c = g[k - H.first[x]];
+                float* o = &row[(size_t)k * 4];
+                o[0] += d0 * c; o[1] += d1 * c; o[2] += d2 * c; o[3] += d3 * c;
+            }
+        }
+        // vertical scatter (:1987-2065)
+        const int j = y + V.margin;
+        for (int k = V.first[j]; k <= V.last[j]; k++)
+        {
+            const float c = V.w[(size_t)j * 4 + (k - V.first[j])];
+            float* o = &acc[(size_t)k * nw * 4];
+            for (int i = 0; i < nw * 4; i++) o[i] += row[i] * c;
+        }
+    }
+    dst.resize((size_t)nw * nh * 4);
+    for (size_t i = 0; i < dst.size(); i++)                               // :1743-1762
+    {
+        float v = acc[i];
+        v = v < 0 ? 0 : (v > 1 ? 1 : v);
+        dst[i] = (unsigned char)(int)((v * 255.0f) + 0.5);
     }
 }
 
@@ -745,7 +854,7 @@ void Image::Load(const std::string& filename)
         if (nw < 1) nw = 1;
         if (nh < 1) nh = 1;
         std::vector<unsigned char> small;
-        downscale_area(rgba, w, h, nw, nh, small);
+        downscale_mitchell(rgba, w, h, nw, nh, small);
         rgba.swap(small);
         w = nw; h = nh;
     }
