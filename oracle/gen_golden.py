@@ -335,6 +335,53 @@ def tier_k_images(ref: Ref, tmp: str):
     add("png_palette", rgb.quantize(16), "PNG")
     add("png_16bit_grey", PI.fromarray((grey.astype(np.uint16) * 257), "I;16"), "PNG")
     add("png_1bit", PI.fromarray(grey > 128).convert("1"), "PNG")
+    # ---- BMP / TGA (the reference's texture dialog offers them, main.cpp:849): Pillow's writers plus
+    # hand-packed headers for the variants Pillow cannot produce
+    import struct
+    small = base[:11, :13]
+    sm = PI.fromarray(small, "RGB")
+    add("bmp_rgb24", sm, "BMP")
+    add("bmp_pal8", sm.quantize(64), "BMP")
+    add("bmp_grey8", PI.fromarray(grey[:11, :13], "L"), "BMP")
+    add("bmp_1bit", PI.fromarray(grey[:11, :13] > 128).convert("1"), "BMP")
+    add("bmp_rgba32", PI.fromarray(np.dstack([small, (xx[:11, :13] * 19 % 256).astype(np.uint8)]), "RGBA"), "BMP")
+    add("tga_rgb", sm, "TGA")
+    add("tga_rgb_rle", PI.fromarray(np.repeat(small[:, ::3], 3, 1)[:, :13].copy(), "RGB"), "TGA", compression="tga_rle")
+    add("tga_rgba", PI.fromarray(np.dstack([small, (xx[:11, :13] * 19 % 256).astype(np.uint8)]), "RGBA"), "TGA")
+    add("tga_grey", PI.fromarray(grey[:11, :13], "L"), "TGA")
+    add("tga_grey_alpha", PI.fromarray(np.dstack([grey[:11, :13], 255 - grey[:11, :13]]), "LA"), "TGA")
+    add("tga_pal", sm.quantize(32), "TGA")
+    add("tga_pal_rle", sm.quantize(8), "TGA", compression="tga_rle")
+
+    def bmp(w, h, bpp, rows, hsz=40, compress=0, masks=b"", palette=b"", top_down=False):
+        body = b"".join(r + b"\0" * ((-len(r)) & 3) for r in rows)
+        if hsz == 12:
+            hdr = struct.pack("<IHHHH", 12, w, h, 1, bpp)
+        else:
+            hdr = struct.pack("<IiiHHIIiiII", hsz, w, -h if top_down else h, 1, bpp, compress, len(body), 2835, 2835, 0, 0)
+            hdr += b"\0" * (hsz - 40) if hsz in (40,) else b""
+        off = 14 + len(hdr) + len(masks) + len(palette)
+        return b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + hdr + masks + palette + body
+    v565 = ((small[..., 0].astype(np.uint16) >> 3) << 11) | ((small[..., 1].astype(np.uint16) >> 2) << 5) | (small[..., 2] >> 3)
+    v555 = ((small[..., 0].astype(np.uint16) >> 3) << 10) | ((small[..., 1].astype(np.uint16) >> 3) << 5) | (small[..., 2] >> 3)
+    cases.append(("bmp_565_bitfields", bmp(13, 11, 16, [v565[y].astype("<u2").tobytes() for y in range(10, -1, -1)], compress=3,
+                                           masks=struct.pack("<III", 0xF800, 0x07E0, 0x001F))))
+    cases.append(("bmp_555_topdown", bmp(13, 11, 16, [v555[y].astype("<u2").tobytes() for y in range(11)], top_down=True)))
+    cases.append(("bmp_32_zero_alpha", bmp(13, 11, 32, [np.dstack([small[y:y + 1, :, ::-1], np.zeros((1, 13, 1), np.uint8)]).tobytes() for y in range(10, -1, -1)])))
+    pal16 = bytes(b for i in range(16) for b in (i * 16, 255 - i * 16, (i * 37) % 256))
+    idx4 = (xx[:11, :13] + yy[:11, :13]) % 16
+    rows4 = [bytes(((int(idx4[y, x]) << 4) | (int(idx4[y, x + 1]) if x + 1 < 13 else 0)) for x in range(0, 13, 2)) for y in range(10, -1, -1)]
+    cases.append(("bmp_os2_4bit", bmp(13, 11, 4, rows4, hsz=12, palette=pal16)))
+
+    def tga(w, h, image_type, bits, data, descriptor=0, cmap=b"", cmap_len=0, cmap_bits=0, ident=b""):
+        return struct.pack("<BBBHHBHHHHBB", len(ident), 1 if cmap else 0, image_type, 0, cmap_len, cmap_bits, 0, 0, w, h, bits, descriptor) + ident + cmap + data
+    cases.append(("tga_rgb16_topdown", tga(13, 11, 2, 16, v555.astype("<u2").tobytes(), descriptor=0x20, ident=b"id")))
+    cases.append(("tga_pal16", tga(13, 11, 1, 8, idx4.astype(np.uint8)[::-1].tobytes(), cmap=np.array([(i * 2113) & 0x7FFF for i in range(16)], "<u2").tobytes(),
+                               cmap_len=16, cmap_bits=16)))
+    rle = b""
+    for y in range(10, -1, -1):                                      # per row: one run packet of 5, one raw packet of 8
+        rle += bytes([0x80 | 4]) + bytes(int(c) for c in small[y, 0, ::-1]) + bytes([7]) + small[y, 5:13, ::-1].tobytes()
+    cases.append(("tga_rle_mixed", tga(13, 11, 10, 24, rle)))
     out = {}
     names = []
     for name, data in cases:

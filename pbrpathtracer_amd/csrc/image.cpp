@@ -2,7 +2,7 @@
 // on stb_image / stb_image_resize) with a small own decoder.  Off the per-sample path: images are
 // decoded once to RGBA8 and uploaded into the device texel atlas by PathTracer::BuildBVH.
 //
-// Formats: binary PNM (P5 / P6, maxval <= 255 or 16-bit), non-interlaced PNG (colour types 0, 2, 3, 4, 6;
+// Formats: BMP and TGA (every variant stb_image 2.27 accepts), binary PNM (P5 / P6, maxval <= 255 or 16-bit), non-interlaced PNG (colour types 0, 2, 3, 4, 6;
 // bit depths 1-16) through zlib, and baseline / extended-sequential Huffman JPEG (grey, YCbCr, RGB).  Everything is expanded to 4 channels the way stbi_load(..., 4)
 // does (grey -> g,g,g,255; 16-bit -> high byte).  Images with a side > 1024 are reduced so the
 // longest side is 1024 (image.cpp:47-60) with stb_image_resize's default downsampling (Mitchell kernel,
@@ -674,6 +674,316 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
     return true;
 }
 
+// ---- BMP and TGA (the reference's texture dialog offers *.jpg;*.jpeg;*.png;*.bmp;*.tga, main.cpp:849) -----
+// Same acceptance rules and pixel arithmetic as stb_image 2.27's loaders (include/stb_image.h:5282-5648 BMP,
+// :5660-5990 TGA) with req_comp = 4, restated over a bounds-checked little-endian reader (reads past the
+// end yield 0, as there).  tests/golden/tier_k_images.npz holds reference-decoded cases of every branch.
+struct LeReader {
+    const unsigned char* b; size_t n, pos = 0;
+    LeReader(const std::vector<unsigned char>& d) : b(d.data()), n(d.size()) {}
+    int u8() { return pos < n ? b[pos++] : 0; }
+    int u16() { int a = u8(); return a | (u8() << 8); }
+    unsigned u32() { unsigned a = (unsigned)u16(); return a | ((unsigned)u16() << 16); }
+    void skip(long k) { if (k < 0) { pos = n; return; } pos = (size_t)k > n - std::min(pos, n) ? n : pos + (size_t)k; }
+};
+
+int top_bit(unsigned z) { int k = -1; while (z) { k++; z >>= 1; } return k; }
+int count_bits(unsigned z) { int k = 0; while (z) { k += (int)(z & 1u); z >>= 1; } return k; }
+
+// a masked channel of `bits` bits whose top bit was moved to bit 7, widened to 8 bits by bit replication
+int widen_channel(unsigned v, int shift, int bits)
+{
+    static const unsigned mul[9] = { 0, 0xff, 0x55, 0x49, 0x11, 0x21, 0x41, 0x81, 0x01 };
+    static const unsigned shr[9] = { 0, 0, 0, 1, 0, 2, 4, 6, 0 };
+    if (shift < 0) v <<= -shift; else v >>= shift;
+    v >>= (8 - bits);
+    return (int)(v * mul[bits]) >> shr[bits];
+}
+
+bool decode_bmp(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgba)
+{
+    LeReader r(d);
+    if (r.u8() != 'B' || r.u8() != 'M') return false;
+    r.u32(); r.u16(); r.u16();
+    const int offset = (int)r.u32();
+    const int hsz = (int)r.u32();
+    if (offset < 0) return false;
+    if (hsz != 12 && hsz != 40 && hsz != 56 && hsz != 108 && hsz != 124) return false;
+    int iw, ih;
+    if (hsz == 12) { iw = r.u16(); ih = r.u16(); } else { iw = (int)r.u32(); ih = (int)r.u32(); }
+    if (r.u16() != 1) return false;
+    const int bpp = r.u16();
+    unsigned mr = 0, mg = 0, mb = 0, ma = 0, all_a = 255;
+    int extra = 14;
+    auto default_masks = [&](int compress) {
+        if (compress != 0) return;
+        if (bpp == 16) { mr = 31u << 10; mg = 31u << 5; mb = 31u; }
+        else if (bpp == 32) { mr = 0xffu << 16; mg = 0xffu << 8; mb = 0xffu; ma = 0xffu << 24; all_a = 0; }
+        else mr = mg = mb = ma = 0;
+    };
+    if (hsz != 12)
+    {
+        const int compress = (int)r.u32();
+        if (compress == 1 || compress == 2) return false;             // RLE is not supported there either
+        if (compress >= 4) return false;
+        if (compress == 3 && bpp != 16 && bpp != 32) return false;
+        r.u32(); r.u32(); r.u32(); r.u32(); r.u32();
+        if (hsz == 40 || hsz == 56)
+        {
+            if (hsz == 56) { r.u32(); r.u32(); r.u32(); r.u32(); }
+            if (bpp == 16 || bpp == 32)
+            {
+                if (compress == 0) default_masks(0);
+                else if (compress == 3)
+                {
+                    mr = r.u32(); mg = r.u32(); mb = r.u32();
+                    extra += 12;
+                    if (mr == mg && mg == mb) return false;
+                }
+                else return false;
+            }
+        }
+        else
+        {
+            mr = r.u32(); mg = r.u32(); mb = r.u32(); ma = r.u32();
+            if (compress != 3) default_masks(compress);
+            r.u32();
+            for (int i = 0; i < 12; i++) r.u32();
+            if (hsz == 124) { r.u32(); r.u32(); r.u32(); r.u32(); }
+        }
+    }
+    const bool flip = ih > 0;                                         // bottom-up rows unless the height is negative
+    ih = std::abs(ih);
+    if (iw <= 0 || ih <= 0 || iw > (1 << 24) || ih > (1 << 24)) return false;
+    int psize = 0;
+    if (hsz == 12) { if (bpp < 24) psize = (offset - extra - 24) / 3; }
+    else if (bpp < 16) psize = (offset - extra - hsz) >> 2;
+    if (psize == 0 && (size_t)offset != r.pos) return false;
+    if ((size_t)iw * ih > (size_t)1 << 28) return false;
+    rgba.assign((size_t)iw * ih * 4, 0);
+    size_t z = 0;
+    if (bpp < 16)
+    {
+        if (psize == 0 || psize > 256) return false;
+        unsigned char pal[256][3];
+        for (int i = 0; i < psize; i++)
+        {
+            pal[i][2] = (unsigned char)r.u8(); pal[i][1] = (unsigned char)r.u8(); pal[i][0] = (unsigned char)r.u8();
+            if (hsz != 12) r.u8();
+        }
+        r.skip((long)offset - extra - hsz - (long)psize * (hsz == 12 ? 3 : 4));
+        int width;
+        if (bpp == 1) width = (iw + 7) >> 3; else if (bpp == 4) width = (iw + 1) >> 1; else if (bpp == 8) width = iw; else return false;
+        const int pad = (-width) & 3;
+        for (int j = 0; j < ih; j++)
+        {
+            if (bpp == 1)
+            {
+                int bit = 7, v = r.u8();
+                for (int i = 0; i < iw; i++)
+                {
+                    const int c = (v >> bit) & 1;
+                    rgba[z++] = pal[c][0]; rgba[z++] = pal[c][1]; rgba[z++] = pal[c][2]; rgba[z++] = 255;
+                    if (i + 1 == iw) break;
+                    if (--bit < 0) { bit = 7; v = r.u8(); }
+                }
+            }
+            else
+            {
+                for (int i = 0; i < iw; i += 2)
+                {
+                    int v = r.u8(), v2 = 0;
+                    if (bpp == 4) { v2 = v & 15; v >>= 4; }
+                    rgba[z++] = pal[v][0]; rgba[z++] = pal[v][1]; rgba[z++] = pal[v][2]; rgba[z++] = 255;
+                    if (i + 1 == iw) break;
+                    v = bpp == 8 ? r.u8() : v2;
+                    rgba[z++] = pal[v][0]; rgba[z++] = pal[v][1]; rgba[z++] = pal[v][2]; rgba[z++] = 255;
+                }
+            }
+            r.skip(pad);
+        }
+    }
+    else
+    {
+        r.skip((long)offset - extra - hsz);
+        int width = bpp == 24 ? 3 * iw : (bpp == 16 ? 2 * iw : 0);
+        const int pad = (-width) & 3;
+        int easy = 0;
+        if (bpp == 24) easy = 1;
+        else if (bpp == 32 && mb == 0xffu && mg == 0xff00u && mr == 0x00ff0000u && ma == 0xff000000u) easy = 2;
+        int rs = 0, gs = 0, bs = 0, as = 0, rc = 0, gc = 0, bc = 0, ac = 0;
+        if (!easy)
+        {
+            if (!mr || !mg || !mb) return false;
+            rs = top_bit(mr) - 7; rc = count_bits(mr);
+            gs = top_bit(mg) - 7; gc = count_bits(mg);
+            bs = top_bit(mb) - 7; bc = count_bits(mb);
+            as = top_bit(ma) - 7; ac = count_bits(ma);
+            if (rc > 8 || gc > 8 || bc > 8 || ac > 8) return false;
+        }
+        for (int j = 0; j < ih; j++)
+        {
+            for (int i = 0; i < iw; i++)
+            {
+                unsigned a;
+                if (easy)
+                {
+                    rgba[z + 2] = (unsigned char)r.u8(); rgba[z + 1] = (unsigned char)r.u8(); rgba[z] = (unsigned char)r.u8();
+                    z += 3;
+                    a = easy == 2 ? (unsigned)r.u8() : 255u;
+                }
+                else
+                {
+                    const unsigned v = bpp == 16 ? (unsigned)r.u16() : r.u32();
+                    rgba[z++] = (unsigned char)widen_channel(v & mr, rs, rc);
+                    rgba[z++] = (unsigned char)widen_channel(v & mg, gs, gc);
+                    rgba[z++] = (unsigned char)widen_channel(v & mb, bs, bc);
+                    a = ma ? (unsigned)widen_channel(v & ma, as, ac) : 255u;
+                }
+                all_a |= a;
+                rgba[z++] = (unsigned char)a;
+            }
+            r.skip(pad);
+        }
+    }
+    if (all_a == 0) for (size_t i = 3; i < rgba.size(); i += 4) rgba[i] = 255;    // an all-zero alpha channel means "no alpha"
+    if (flip)
+        for (int j = 0; j < ih >> 1; j++)
+            std::swap_ranges(rgba.begin() + (size_t)j * iw * 4, rgba.begin() + (size_t)(j + 1) * iw * 4, rgba.begin() + (size_t)(ih - 1 - j) * iw * 4);
+    w = iw; h = ih;
+    return true;
+}
+
+// components of a TGA pixel / palette entry (0 = unsupported); 15/16-bit colour decodes as 5-5-5 RGB
+int tga_components(int bits, bool grey, bool* rgb16)
+{
+    *rgb16 = false;
+    switch (bits)
+    {
+    case 8: return 1;
+    case 16: if (grey) return 2;          // grey + alpha
+             // fall through
+    case 15: *rgb16 = true; return 3;
+    case 24: case 32: return bits / 8;
+    default: return 0;
+    }
+}
+
+bool decode_tga(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgba)
+{
+    {   // the acceptance test (stb_image.h:5742-5772)
+        LeReader t(d);
+        t.u8();
+        const int ctype = t.u8();
+        if (ctype > 1) return false;
+        int sz = t.u8();
+        if (ctype == 1)
+        {
+            if (sz != 1 && sz != 9) return false;
+            t.skip(4);
+            sz = t.u8();
+            if (sz != 8 && sz != 15 && sz != 16 && sz != 24 && sz != 32) return false;
+            t.skip(4);
+        }
+        else
+        {
+            if (sz != 2 && sz != 3 && sz != 10 && sz != 11) return false;
+            t.skip(9);
+        }
+        if (t.u16() < 1 || t.u16() < 1) return false;
+        sz = t.u8();
+        if (ctype == 1 && sz != 8 && sz != 16) return false;
+        if (sz != 8 && sz != 15 && sz != 16 && sz != 24 && sz != 32) return false;
+    }
+    LeReader r(d);
+    const int id_len = r.u8();
+    const int indexed = r.u8();
+    int image_type = r.u8();
+    const int pal_start = r.u16(), pal_len = r.u16(), pal_bits = r.u8();
+    r.u16(); r.u16();
+    const int tw = r.u16(), th = r.u16();
+    const int bits = r.u8();
+    int inverted = r.u8();
+    bool rle = false;
+    if (image_type >= 8) { image_type -= 8; rle = true; }
+    inverted = 1 - ((inverted >> 5) & 1);                              // 1 = rows stored bottom-up
+    bool rgb16 = false;
+    const int comp = indexed ? tga_components(pal_bits, false, &rgb16) : tga_components(bits, image_type == 3, &rgb16);
+    if (!comp) return false;
+    std::vector<unsigned char> px((size_t)tw * th * comp, 0), pal;
+    r.skip(id_len);
+    auto read_rgb16 = [&](unsigned char* o) {
+        const unsigned v = (unsigned)r.u16();
+        o[0] = (unsigned char)((((v >> 10) & 31) * 255) / 31);
+        o[1] = (unsigned char)((((v >> 5) & 31) * 255) / 31);
+        o[2] = (unsigned char)(((v & 31) * 255) / 31);
+    };
+    if (!indexed && !rle && !rgb16)
+    {
+        for (int i = 0; i < th; i++)
+        {
+            unsigned char* row = &px[(size_t)(inverted ? th - i - 1 : i) * tw * comp];
+            for (int k = 0; k < tw * comp; k++) row[k] = (unsigned char)r.u8();
+        }
+    }
+    else
+    {
+        if (indexed)
+        {
+            if (pal_len == 0) return false;
+            r.skip(pal_start);
+            pal.assign((size_t)pal_len * comp, 0);
+            if (rgb16) for (int i = 0; i < pal_len; i++) read_rgb16(&pal[(size_t)i * comp]);
+            else
+            {
+                if (r.pos + pal.size() > r.n) return false;
+                for (size_t i = 0; i < pal.size(); i++) pal[i] = (unsigned char)r.u8();
+            }
+        }
+        unsigned char raw[4] = { 0, 0, 0, 0 };
+        int run = 0; bool repeating = false, fetch = true;
+        for (size_t i = 0; i < (size_t)tw * th; i++)
+        {
+            if (rle)
+            {
+                if (run == 0) { const int cmd = r.u8(); run = 1 + (cmd & 127); repeating = (cmd >> 7) != 0; fetch = true; }
+                else if (!repeating) fetch = true;
+            }
+            else fetch = true;
+            if (fetch)
+            {
+                if (indexed)
+                {
+                    int idx = bits == 8 ? r.u8() : r.u16();
+                    if (idx >= pal_len) idx = 0;
+                    for (int j = 0; j < comp; j++) raw[j] = pal[(size_t)idx * comp + j];
+                }
+                else if (rgb16) read_rgb16(raw);
+                else for (int j = 0; j < comp; j++) raw[j] = (unsigned char)r.u8();
+                fetch = false;
+            }
+            for (int j = 0; j < comp; j++) px[i * comp + j] = raw[j];
+            --run;
+        }
+        if (inverted)
+            for (int j = 0; j * 2 < th; j++)
+                std::swap_ranges(px.begin() + (size_t)j * tw * comp, px.begin() + (size_t)(j + 1) * tw * comp, px.begin() + (size_t)(th - 1 - j) * tw * comp);
+    }
+    if (comp >= 3 && !rgb16) for (size_t i = 0; i < (size_t)tw * th; i++) std::swap(px[i * comp], px[i * comp + 2]);   // BGR(A) on disk
+    rgba.resize((size_t)tw * th * 4);
+    for (size_t i = 0; i < (size_t)tw * th; i++)
+    {
+        const unsigned char* s = &px[i * comp];
+        unsigned char* o = &rgba[i * 4];
+        if (comp == 1) { o[0] = o[1] = o[2] = s[0]; o[3] = 255; }
+        else if (comp == 2) { o[0] = o[1] = o[2] = s[0]; o[3] = s[1]; }
+        else if (comp == 3) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = 255; }
+        else { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; }
+    }
+    w = tw; h = th;
+    return true;
+}
+
 // ---- reduction of images with a side > 1024 (image.cpp:47-60) ---------------------------------------
 // The reference calls stbir_resize_uint8(src, w, h, 0, dst, nw, nh, 0, 4) of stb_image_resize v0.97
 // (include/stb_image_resize.h:2462-2470): linear colour space, no alpha weighting, clamped edges and the
@@ -845,7 +1155,9 @@ void Image::Load(const std::string& filename)
     std::vector<unsigned char> file, rgba;
     int w = 0, h = 0;
     if (!read_file(filename, file)) return;                       // missing file -> mData == 0 -> sampler returns 0
-    if (!decode_pnm(file, w, h, rgba) && !decode_png(file, w, h, rgba) && !decode_jpeg(file, w, h, rgba)) return;
+    // probe order of stbi__load_main (stb_image.h:1125-1166): PNG, BMP, ... JPEG, PNM, and TGA last (weakest signature)
+    if (!decode_png(file, w, h, rgba) && !decode_bmp(file, w, h, rgba) && !decode_jpeg(file, w, h, rgba) &&
+        !decode_pnm(file, w, h, rgba) && !decode_tga(file, w, h, rgba)) return;
     if (w > 1024 || h > 1024)
     {
         float scale = 1024.f / fmax(w, h);                        // image.cpp:49
