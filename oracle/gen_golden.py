@@ -328,6 +328,12 @@ def tier_k_images(ref: Ref, tmp: str):
     add("jpg_tiny_1x1", PI.fromarray(base[:1, :1], "RGB"), "JPEG", quality=90)
     add("jpg_odd_17x9_420", PI.fromarray(base[:9, :17], "RGB"), "JPEG", quality=70, subsampling=2)
     add("jpg_q100_444", rgb, "JPEG", quality=100, subsampling=0)
+    add("jpg_prog_420_q80", rgb, "JPEG", quality=80, subsampling=2, progressive=True)
+    add("jpg_prog_444_q95", rgb, "JPEG", quality=95, subsampling=0, progressive=True)
+    add("jpg_prog_422_q40_opt", rgb, "JPEG", quality=40, subsampling=1, progressive=True, optimize=True)
+    add("jpg_prog_grey", PI.fromarray(grey, "L"), "JPEG", quality=70, progressive=True)
+    add("jpg_prog_odd_17x9", PI.fromarray(base[:9, :17], "RGB"), "JPEG", quality=85, subsampling=2, progressive=True)
+    add("jpg_prog_restart", rgb, "JPEG", quality=75, subsampling=2, progressive=True, restart_marker_blocks=3)
     add("png_rgb", rgb, "PNG")
     add("png_rgba", PI.fromarray(np.dstack([base, (xx * 4 % 256).astype(np.uint8)]), "RGBA"), "PNG")
     add("png_grey", PI.fromarray(grey, "L"), "PNG")

@@ -3,7 +3,7 @@
 // decoded once to RGBA8 and uploaded into the device texel atlas by PathTracer::BuildBVH.
 //
 // Formats: BMP and TGA (every variant stb_image 2.27 accepts), binary PNM (P5 / P6, maxval <= 255 or 16-bit), non-interlaced PNG (colour types 0, 2, 3, 4, 6;
-// bit depths 1-16) through zlib, and baseline / extended-sequential Huffman JPEG (grey, YCbCr, RGB).  Everything is expanded to 4 channels the way stbi_load(..., 4)
+// bit depths 1-16) through zlib, and baseline / extended-sequential / progressive Huffman JPEG (grey, YCbCr, RGB).  Everything is expanded to 4 channels the way stbi_load(..., 4)
 // does (grey -> g,g,g,255; 16-bit -> high byte).  Images with a side > 1024 are reduced so the
 // longest side is 1024 (image.cpp:47-60) with stb_image_resize's default downsampling (Mitchell kernel,
 // clamped edges), bit-identically (tests/golden/tier_k_resize.npz).
@@ -218,6 +218,8 @@ struct JpegComp {
     int id, h, v, tq, hd, ha, dc_pred;
     int x, y, w2, h2;
     std::vector<unsigned char> data;
+    std::vector<short> coeff;            // progressive: 64 coefficients per block of the padded plane, natural order
+    int coeff_w = 0;                     // blocks per row of that plane
 };
 
 struct JpegDec {
@@ -229,6 +231,8 @@ struct JpegDec {
     int ncomp = 0, w = 0, h = 0, h_max = 1, v_max = 1, mcu_x = 0, mcu_y = 0, restart_interval = 0, todo = 0;
     int jfif = 0, app14 = -1, rgb = 0;
     int scan_n = 0, order[4];
+    bool progressive = false;
+    int spec_start = 0, spec_end = 63, succ_high = 0, succ_low = 0, eob_run = 0;
 
     int get8() { return p < end ? *p++ : 0; }
     int get16() { int a = get8(); return (a << 8) | get8(); }
@@ -272,8 +276,26 @@ struct JpegDec {
         static const int bias[16] = { 0, -1, -3, -7, -15, -31, -63, -127, -255, -511, -1023, -2047, -4095, -8191, -16383, -32767 };
         return (int)k + (bias[n] & (sgn - 1));
     }
+    unsigned get_bits(int n)
+    {
+        if (bitcnt < n) grow();
+        unsigned k = (bitbuf << n) | (bitbuf >> (32 - n));
+        bitbuf = k & ~((1u << n) - 1);
+        k &= (1u << n) - 1;
+        bitcnt -= n;
+        return k;
+    }
+    bool get_bit()
+    {
+        if (bitcnt < 1) grow();
+        const unsigned k = bitbuf;
+        bitbuf <<= 1;
+        --bitcnt;
+        return (k & 0x80000000u) != 0;
+    }
     void reset()
     {
+        eob_run = 0;
         bitbuf = 0; bitcnt = 0; nomore = false; marker = 0xff;
         for (int i = 0; i < 4; i++) comp[i].dc_pred = 0;
         todo = restart_interval ? restart_interval : 0x7fffffff;
@@ -371,6 +393,170 @@ static bool jpeg_block(JpegDec& z, short* data, int n)
         }
     } while (k < 64);
     return true;
+}
+
+// progressive JPEG, DC scans (first pass and successive-approximation refinement): stb_image.h:2234-2258
+static bool jpeg_block_prog_dc(JpegDec& z, short* data, int n)
+{
+    if (z.spec_end != 0) return false;
+    if (z.bitcnt < 16) z.grow();
+    if (z.succ_high == 0)
+    {
+        std::memset(data, 0, 64 * sizeof(short));
+        int t = z.decode(z.hdc[z.comp[n].hd]);
+        if (t < 0 || t > 15) return false;
+        int diff = t ? z.extend_receive(t) : 0;
+        int dc = z.comp[n].dc_pred + diff;
+        z.comp[n].dc_pred = dc;
+        data[0] = (short)(dc * (1 << z.succ_low));
+    }
+    else if (z.get_bit()) data[0] += (short)(1 << z.succ_low);
+    return true;
+}
+
+// progressive JPEG, AC scans (spectral band spec_start..spec_end; first pass with end-of-band runs, or
+// refinement of one more bit): stb_image.h:2262-2379
+static bool jpeg_block_prog_ac(JpegDec& z, short* data, const JpegHuff& hac)
+{
+    if (z.spec_start == 0) return false;
+    if (z.succ_high == 0)
+    {
+        const int shift = z.succ_low;
+        if (z.eob_run) { --z.eob_run; return true; }
+        int k = z.spec_start;
+        do
+        {
+            if (z.bitcnt < 16) z.grow();
+            int rs = z.decode(hac);
+            if (rs < 0) return false;
+            int s = rs & 15, r = rs >> 4;
+            if (s == 0)
+            {
+                if (r < 15)
+                {
+                    z.eob_run = 1 << r;
+                    if (r) z.eob_run += (int)z.get_bits(r);
+                    --z.eob_run;
+                    break;
+                }
+                k += 16;
+            }
+            else
+            {
+                k += r;
+                unsigned zig = kJpegDezigzag[k++];
+                data[zig] = (short)(z.extend_receive(s) * (1 << shift));
+            }
+        } while (k <= z.spec_end);
+        return true;
+    }
+    const short bit = (short)(1 << z.succ_low);
+    auto refine = [&](short* p) {
+        if (z.get_bit() && (*p & bit) == 0) { if (*p > 0) *p += bit; else *p -= bit; }
+    };
+    if (z.eob_run)
+    {
+        --z.eob_run;
+        for (int k = z.spec_start; k <= z.spec_end; k++)
+        {
+            short* p = &data[kJpegDezigzag[k]];
+            if (*p != 0) refine(p);
+        }
+        return true;
+    }
+    int k = z.spec_start;
+    do
+    {
+        int rs = z.decode(hac);
+        if (rs < 0) return false;
+        int s = rs & 15, r = rs >> 4;
+        if (s == 0)
+        {
+            if (r < 15)
+            {
+                z.eob_run = (1 << r) - 1;
+                if (r) z.eob_run += (int)z.get_bits(r);
+                r = 64;                                       // rest of the band: refinements only
+            }
+        }
+        else
+        {
+            if (s != 1) return false;
+            s = z.get_bit() ? bit : -bit;
+        }
+        while (k <= z.spec_end)
+        {
+            short* p = &data[kJpegDezigzag[k++]];
+            if (*p != 0) refine(p);
+            else
+            {
+                if (r == 0) { *p = (short)s; break; }
+                --r;
+            }
+        }
+    } while (k <= z.spec_end);
+    return true;
+}
+
+static bool jpeg_scan_progressive(JpegDec& z)
+{
+    z.reset();
+    auto restart = [&]() -> int {                                 // 0 keep going, 1 stop the scan
+        if (--z.todo > 0) return 0;
+        if (z.bitcnt < 24) z.grow();
+        if (!(z.marker >= 0xd0 && z.marker <= 0xd7)) return 1;
+        z.reset();
+        return 0;
+    };
+    if (z.scan_n == 1)
+    {
+        const int n = z.order[0];
+        JpegComp& c = z.comp[n];
+        const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+        for (int j = 0; j < bh; j++)
+            for (int i = 0; i < bw; i++)
+            {
+                short* data = &c.coeff[(size_t)64 * (i + (size_t)j * c.coeff_w)];
+                if (z.spec_start == 0) { if (!jpeg_block_prog_dc(z, data, n)) return false; }
+                else if (!jpeg_block_prog_ac(z, data, z.hac[c.ha])) return false;
+                if (restart()) return true;
+            }
+        return true;
+    }
+    for (int j = 0; j < z.mcu_y; j++)
+        for (int i = 0; i < z.mcu_x; i++)
+        {
+            for (int k = 0; k < z.scan_n; k++)
+            {
+                const int n = z.order[k];
+                JpegComp& c = z.comp[n];
+                for (int y = 0; y < c.v; y++)
+                    for (int x = 0; x < c.h; x++)
+                    {
+                        const int x2 = i * c.h + x, y2 = j * c.v + y;
+                        if (!jpeg_block_prog_dc(z, &c.coeff[(size_t)64 * (x2 + (size_t)y2 * c.coeff_w)], n)) return false;
+                    }
+            }
+            if (restart()) return true;
+        }
+    return true;
+}
+
+// after the last scan of a progressive file: dequantise and transform every block (stb_image.h:3046-3064)
+static void jpeg_finish_progressive(JpegDec& z)
+{
+    for (int n = 0; n < z.ncomp; n++)
+    {
+        JpegComp& c = z.comp[n];
+        const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+        for (int j = 0; j < bh; j++)
+            for (int i = 0; i < bw; i++)
+            {
+                short* data = &c.coeff[(size_t)64 * (i + (size_t)j * c.coeff_w)];
+                for (int k = 0; k < 64; k++) data[k] = (short)(data[k] * z.dequant[c.tq][k]);
+                jpeg_idct(&c.data[(size_t)c.w2 * j * 8 + i * 8], c.w2, data);
+            }
+    }
 }
 
 static bool jpeg_scan(JpegDec& z)
@@ -483,8 +669,9 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
     while (m != 0xd9)
     {
         if (z.p >= z.end) break;
-        if (m == 0xc0 || m == 0xc1)                               // SOF0 / SOF1
+        if (m == 0xc0 || m == 0xc1 || m == 0xc2)                  // SOF0 / SOF1 / SOF2 (progressive)
         {
+            z.progressive = m == 0xc2;
             int Lf = z.get16(); int prec = z.get8();
             if (prec != 8) return false;
             z.h = z.get16(); z.w = z.get16();
@@ -515,10 +702,14 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
                 c.y = (z.h * c.v + z.v_max - 1) / z.v_max;
                 c.w2 = z.mcu_x * c.h * 8; c.h2 = z.mcu_y * c.v * 8;
                 c.data.assign((size_t)c.w2 * c.h2, 0);
+                if (z.progressive)
+                {
+                    c.coeff_w = c.w2 / 8;
+                    c.coeff.assign((size_t)c.w2 * c.h2, 0);
+                }
             }
             have_frame = true;
         }
-        else if (m == 0xc2) return false;                          // progressive: unsupported
         else if (m == 0xc4)                                        // DHT
         {
             int L = z.get16() - 2;
@@ -563,8 +754,19 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
                 if (z.comp[which].hd > 3 || z.comp[which].ha > 3) return false;
                 z.order[i] = which;
             }
-            z.get8(); z.get8(); z.get8();                          // Ss, Se, Ah/Al (baseline: 0, 63, 0)
-            if (!jpeg_scan(z)) return false;
+            z.spec_start = z.get8(); z.spec_end = z.get8();
+            { const int aa = z.get8(); z.succ_high = aa >> 4; z.succ_low = aa & 15; }
+            if (z.progressive)
+            {
+                if (z.spec_start > 63 || z.spec_end > 63 || z.spec_start > z.spec_end || z.succ_high > 13 || z.succ_low > 13) return false;
+                if (!jpeg_scan_progressive(z)) return false;
+            }
+            else
+            {
+                if (z.spec_start != 0 || z.succ_high != 0 || z.succ_low != 0) return false;
+                z.spec_end = 63;
+                if (!jpeg_scan(z)) return false;
+            }
             decoded = true;
             if (z.marker == 0xff)
             {
@@ -617,6 +819,7 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
         m = next_marker();
     }
     if (!decoded) return false;
+    if (z.progressive) jpeg_finish_progressive(z);
 
     // resample + colour convert, forced to 4 channels (stbi_load(..., 4))
     w = z.w; h = z.h;
