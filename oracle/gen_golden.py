@@ -341,9 +341,57 @@ def tier_k_images(ref: Ref, tmp: str):
     add("png_palette", rgb.quantize(16), "PNG")
     add("png_16bit_grey", PI.fromarray((grey.astype(np.uint16) * 257), "I;16"), "PNG")
     add("png_1bit", PI.fromarray(grey > 128).convert("1"), "PNG")
+    # ---- PNG variants Pillow cannot write: Adam7 interlace, colour-key tRNS at 16 bits
+    import zlib
+
+    def png_manual(a, depth, ctype, interlace=False, trns=None, plte=None):
+        """a: [h, w, channels] integer samples at `depth` bits."""
+        hh, ww, ch = a.shape
+
+        def rows(sub):
+            out = b""
+            for r in sub:
+                flat = r.reshape(-1)
+                if depth == 8:
+                    data = flat.astype(np.uint8).tobytes()
+                elif depth == 16:
+                    data = flat.astype(">u2").tobytes()
+                else:
+                    bits = "".join(format(int(v), "0%db" % depth) for v in flat)
+                    bits += "0" * ((-len(bits)) % 8)
+                    data = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+                out += b"\0" + data
+            return out
+        if interlace:
+            x0 = [0, 4, 0, 2, 0, 1, 0]; y0 = [0, 0, 4, 0, 2, 0, 1]; dx = [8, 8, 4, 4, 2, 2, 1]; dy = [8, 8, 8, 4, 4, 2, 2]
+            raw = b"".join(rows(a[y0[p]::dy[p], x0[p]::dx[p]]) for p in range(7) if a[y0[p]::dy[p], x0[p]::dx[p]].size)
+        else:
+            raw = rows(a)
+
+        def chunk(tag, data):
+            return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+        out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", ww, hh, depth, ctype, 0, 0, 1 if interlace else 0))
+        if plte is not None:
+            out += chunk(b"PLTE", plte)
+        if trns is not None:
+            out += chunk(b"tRNS", trns)
+        return out + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+    import struct
+    b19 = base[:19, :21].astype(np.int64)
+    cases.append(("png_adam7_rgb", png_manual(b19, 8, 2, interlace=True)))
+    cases.append(("png_adam7_rgba16", png_manual(np.dstack([b19 * 257, (b19[..., :1] * 131) % 65536]), 16, 6, interlace=True)))
+    cases.append(("png_adam7_grey2_3x5", png_manual((b19[:5, :3, :1] // 64), 2, 0, interlace=True)))
+    cases.append(("png_adam7_pal4", png_manual(((b19[..., :1] // 16) % 16), 4, 3, interlace=True, plte=bytes(range(48)), trns=bytes([0, 128, 255]))))
+    cases.append(("png_adam7_1x1", png_manual(b19[:1, :1], 8, 2, interlace=True)))
+    g16 = (b19[..., :1] * 257) % 65536
+    cases.append(("png_grey16_key", png_manual(g16, 16, 0, trns=struct.pack(">H", int(g16[3, 4, 0])))))
+    cases.append(("png_rgb16_key", png_manual(b19 * 257, 16, 2, trns=struct.pack(">HHH", *[int(v) * 257 for v in b19[2, 5]]))))
+    add("png_grey_key", PI.fromarray(grey, "L"), "PNG", transparency=int(grey[5, 5]))
+    add("png_rgb_key", rgb, "PNG", transparency=tuple(int(v) for v in base[7, 9]))
+    cases.append(("png_grey4_key", png_manual((b19[..., :1] // 16), 4, 0, trns=struct.pack(">H", 7))))
+
     # ---- BMP / TGA (the reference's texture dialog offers them, main.cpp:849): Pillow's writers plus
     # hand-packed headers for the variants Pillow cannot produce
-    import struct
     small = base[:11, :13]
     sm = PI.fromarray(small, "RGB")
     add("bmp_rgb24", sm, "BMP")

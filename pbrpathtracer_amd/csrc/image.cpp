@@ -2,7 +2,7 @@
 // on stb_image / stb_image_resize) with a small own decoder.  Off the per-sample path: images are
 // decoded once to RGBA8 and uploaded into the device texel atlas by PathTracer::BuildBVH.
 //
-// Formats: BMP and TGA (every variant stb_image 2.27 accepts), binary PNM (P5 / P6, maxval <= 255 or 16-bit), non-interlaced PNG (colour types 0, 2, 3, 4, 6;
+// Formats: BMP and TGA (every variant stb_image 2.27 accepts), binary PNM (P5 / P6, maxval <= 255 or 16-bit), PNG incl. Adam7 interlace and colour-key tRNS (colour types 0, 2, 3, 4, 6;
 // bit depths 1-16) through zlib, and baseline / extended-sequential / progressive Huffman JPEG (grey, YCbCr, RGB).  Everything is expanded to 4 channels the way stbi_load(..., 4)
 // does (grey -> g,g,g,255; 16-bit -> high byte).  Images with a side > 1024 are reduced so the
 // longest side is 1024 (image.cpp:47-60) with stb_image_resize's default downsampling (Mitchell kernel,
@@ -113,66 +113,100 @@ bool decode_png(const std::vector<unsigned char>& d, int& w, int& h, std::vector
         else if (!std::memcmp(type, "IEND", 4)) break;
         pos += 12 + (size_t)len;
     }
-    if (!have_ihdr || w <= 0 || h <= 0 || w > (1 << 15) || h > (1 << 15) || interlace != 0) return false;
+    if (!have_ihdr || w <= 0 || h <= 0 || w > (1 << 15) || h > (1 << 15) || interlace > 1) return false;
     int channels;
     switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break;
                      case 4: channels = 2; break; case 6: channels = 4; break; default: return false; }
     if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) return false;
     if (depth < 8 && !(ctype == 0 || ctype == 3)) return false;
-    size_t bpp_bits = (size_t)channels * depth;
-    size_t stride = ((size_t)w * bpp_bits + 7) / 8;
-    size_t bpp = (bpp_bits + 7) / 8;
-    std::vector<unsigned char> raw((stride + 1) * (size_t)h);
+    const size_t bpp_bits = (size_t)channels * depth;
+    const size_t bpp = (bpp_bits + 7) / 8;
+    // the image is one pass, or the seven Adam7 passes (each a smaller image with its own scanlines and filters)
+    static const int x0[7] = { 0, 4, 0, 2, 0, 1, 0 }, y0[7] = { 0, 0, 4, 0, 2, 0, 1 };
+    static const int dx[7] = { 8, 8, 4, 4, 2, 2, 1 }, dy[7] = { 8, 8, 8, 4, 4, 2, 2 };
+    const int npass = interlace ? 7 : 1;
+    size_t total = 0;
+    int pw[7], ph[7];
+    for (int p = 0; p < npass; p++)
+    {
+        pw[p] = interlace ? (w - x0[p] + dx[p] - 1) / dx[p] : w;
+        ph[p] = interlace ? (h - y0[p] + dy[p] - 1) / dy[p] : h;
+        if (pw[p] > 0 && ph[p] > 0) total += (((size_t)pw[p] * bpp_bits + 7) / 8 + 1) * (size_t)ph[p];
+    }
+    std::vector<unsigned char> raw(total);
     uLongf dlen = (uLongf)raw.size();
     if (uncompress(raw.data(), &dlen, idat.data(), (uLong)idat.size()) != Z_OK || dlen != raw.size()) return false;
-    // unfilter in place
-    std::vector<unsigned char> prev(stride, 0);
-    std::vector<unsigned char> img(stride * (size_t)h);
-    for (int y = 0; y < h; y++)
+    std::vector<unsigned short> samp((size_t)w * h * channels);      // sample values at the file's bit depth
+    size_t at = 0;
+    for (int p = 0; p < npass; p++)
     {
-        const unsigned char* src = &raw[(stride + 1) * (size_t)y];
-        unsigned char* cur = &img[stride * (size_t)y];
-        int ft = src[0];
-        for (size_t x = 0; x < stride; x++)
+        if (pw[p] <= 0 || ph[p] <= 0) continue;
+        const size_t stride = ((size_t)pw[p] * bpp_bits + 7) / 8;
+        std::vector<unsigned char> prev(stride, 0), cur(stride);
+        for (int y = 0; y < ph[p]; y++)
         {
-            int a = x >= bpp ? cur[x - bpp] : 0, b = prev[x], c = x >= bpp ? prev[x - bpp] : 0;
-            int v = src[1 + x];
-            switch (ft) { case 0: break; case 1: v += a; break; case 2: v += b; break;
-                          case 3: v += (a + b) / 2; break; case 4: v += paeth(a, b, c); break; default: return false; }
-            cur[x] = (unsigned char)v;
-        }
-        std::memcpy(prev.data(), cur, stride);
-    }
-    rgba.resize((size_t)w * h * 4);
-    for (int y = 0; y < h; y++)
-    {
-        const unsigned char* row = &img[stride * (size_t)y];
-        for (int x = 0; x < w; x++)
-        {
-            unsigned char s[4] = { 0, 0, 0, 255 };
-            for (int k = 0; k < channels; k++)
+            const unsigned char* src = &raw[at];
+            at += stride + 1;
+            const int ft = src[0];
+            for (size_t x = 0; x < stride; x++)
             {
-                if (depth == 8) s[k] = row[(size_t)x * channels + k];
-                else if (depth == 16) s[k] = row[((size_t)x * channels + k) * 2];
-                else
+                int a = x >= bpp ? cur[x - bpp] : 0, b = prev[x], c = x >= bpp ? prev[x - bpp] : 0;
+                int v = src[1 + x];
+                switch (ft) { case 0: break; case 1: v += a; break; case 2: v += b; break;
+                              case 3: v += (a + b) / 2; break; case 4: v += paeth(a, b, c); break; default: return false; }
+                cur[x] = (unsigned char)v;
+            }
+            const int oy = interlace ? y * dy[p] + y0[p] : y;
+            for (int x = 0; x < pw[p]; x++)
+            {
+                const int ox = interlace ? x * dx[p] + x0[p] : x;
+                unsigned short* o = &samp[((size_t)oy * w + ox) * channels];
+                for (int k = 0; k < channels; k++)
                 {
-                    size_t bit = (size_t)x * depth;
-                    int v = (row[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1);
-                    s[k] = ctype == 3 ? (unsigned char)v : (unsigned char)(v * 255 / ((1 << depth) - 1));
+                    if (depth == 8) o[k] = cur[(size_t)x * channels + k];
+                    else if (depth == 16) o[k] = (unsigned short)((cur[((size_t)x * channels + k) * 2] << 8) | cur[((size_t)x * channels + k) * 2 + 1]);
+                    else
+                    {
+                        const size_t bit = (size_t)x * depth;
+                        o[k] = (unsigned short)((cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1));
+                    }
                 }
             }
-            unsigned char* o = &rgba[((size_t)y * w + x) * 4];
-            if (ctype == 0) { o[0] = o[1] = o[2] = s[0]; o[3] = 255; }
-            else if (ctype == 2) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = 255; }
-            else if (ctype == 4) { o[0] = o[1] = o[2] = s[0]; o[3] = s[1]; }
-            else if (ctype == 6) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; }
-            else
-            {
-                size_t idx = s[0];
-                if (idx * 3 + 2 < plte.size()) { o[0] = plte[idx * 3]; o[1] = plte[idx * 3 + 1]; o[2] = plte[idx * 3 + 2]; }
-                else { o[0] = o[1] = o[2] = 0; }
-                o[3] = idx < trns.size() ? trns[idx] : 255;
-            }
+            prev.swap(cur);
+        }
+    }
+    // tRNS on a grey / RGB image names ONE transparent colour (compared at the file's bit depth)
+    const bool key = (ctype == 0 && trns.size() >= 2) || (ctype == 2 && trns.size() >= 6);
+    unsigned short keyv[3] = { 0, 0, 0 };
+    if (key) for (int k = 0; k < channels; k++) keyv[k] = (unsigned short)(((trns[2 * k] << 8) | trns[2 * k + 1]) & (depth == 16 ? 0xffff : 0xff));
+    rgba.resize((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++)
+    {
+        const unsigned short* v = &samp[i * channels];
+        unsigned char s[4] = { 0, 0, 0, 255 };
+        for (int k = 0; k < channels; k++)
+        {
+            if (depth == 8) s[k] = (unsigned char)v[k];
+            else if (depth == 16) s[k] = (unsigned char)(v[k] >> 8);
+            else s[k] = ctype == 3 ? (unsigned char)v[k] : (unsigned char)(v[k] * 255 / ((1 << depth) - 1));
+        }
+        unsigned char* o = &rgba[i * 4];
+        if (ctype == 0) { o[0] = o[1] = o[2] = s[0]; o[3] = 255; }
+        else if (ctype == 2) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = 255; }
+        else if (ctype == 4) { o[0] = o[1] = o[2] = s[0]; o[3] = s[1]; }
+        else if (ctype == 6) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; }
+        else
+        {
+            size_t idx = s[0];
+            if (idx * 3 + 2 < plte.size()) { o[0] = plte[idx * 3]; o[1] = plte[idx * 3 + 1]; o[2] = plte[idx * 3 + 2]; }
+            else { o[0] = o[1] = o[2] = 0; }
+            o[3] = idx < trns.size() ? trns[idx] : 255;
+        }
+        if (key)
+        {
+            bool same = true;
+            for (int k = 0; k < channels; k++) same = same && v[k] == keyv[k];
+            if (same) o[3] = 0;
         }
     }
     return true;
