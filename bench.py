@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+VALU_PEAK_TFLOPS = 157.3     # FP32 vector: 256 CUs x 128 lanes x 2 flops (FMA) x 2.4 GHz
 
 # device record sizes (pbrpathtracer_amd/csrc/ptk_device.h) -> algorithmic bytes, DESIGN.md §Roofline
 BYTES_NODE = 64              # BVH2 node record: two child boxes + two child links
@@ -213,9 +214,6 @@ def main():
     if rank == 0:
         # algorithmic bytes from the kernel's own traversal counts (untimed counters-enabled variant)
         ntri_for_chunk = ctx.bvh_info()[2]
-        ctx.set_tile(0, 1)
-        stats = ctx.collect_stats(0, min(spp, 8), args.seed)
-        ctx.set_tile(rank, world)
         # ptk's automatic samples per work item (ptk_api.hip run_passes)
         from pbrpathtracer_amd.distributed import owned_tile_count
         per_item = spp * owned_tile_count(W, H, rank, world) * 4.0 / 49152.0
@@ -223,12 +221,24 @@ def main():
         while chunk * 2 <= max_chunk and chunk * 2 <= per_item:
             chunk *= 2
         chunk = min(chunk, spp)
+        # counters over a few chunks of the whole frame, with the work-item size the timed launches used
+        ctx.set_tile(0, 1)
+        ctx.set_option("chunk", chunk)
+        stats = ctx.collect_stats(0, min(spp, 2 * chunk), args.seed)
+        ctx.set_option("chunk", 0)
+        ctx.set_tile(rank, world)
         flat = ntri_for_chunk <= 16
         bps = algorithmic_bytes_per_sample(stats, chunk, flat)
         launch_samples = float(W) * H * spp / world
         avg_ms = float(np.mean(ev_ms))
         achieved = bps * launch_samples / (avg_ms * 1e-3) / 1e9
         s = float(stats["samples"])
+        # SURVEY.md §8(d4)'s own per-unit figures, for cross-checking: a visited node here holds BOTH child
+        # boxes = two of its 32-B node records / two of its 30-flop box tests
+        d4_bytes = (27.0 + stats["node_visits"] / s * 2 * 32 + stats["tri_tests"] / s * 36
+                    + stats["hits_shaded"] / s * (104 + 48) + stats["tex_fetches"] / s * 4)
+        d4_flops = stats["node_visits"] / s * 2 * 30 + stats["tri_tests"] / s * 50 + stats["hits_shaded"] / s * 250
+        valu_tflops = d4_flops * launch_samples / (avg_ms * 1e-3) / 1e12
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -242,8 +252,16 @@ def main():
             "simd_lane_utilisation": {"walk": round(stats["walk_lane_iters"] / max(1, stats["walk_wave_iters"]) / 64.0, 3),
                                       "shade": round(stats["shade_lanes"] / max(1, stats["shade_wave_execs"]) / 64.0, 3),
                                       "camera": round(stats["gen_lanes"] / max(1, stats["gen_wave_execs"]) / 64.0, 3)},
-            "note": "the working set of this config is cache-resident: the algorithmic bytes are served by the scalar cache / "
-                    "L1 / L2, HBM sees only `traffic`; the kernel is VALU-issue- and divergence-bound (DESIGN.md §5)",
+            "survey_d4": {"bytes_per_sample": round(d4_bytes, 1),
+                          "achieved_GBps": round(d4_bytes * launch_samples / (avg_ms * 1e-3) / 1e9, 1),
+                          "frac": round(d4_bytes * launch_samples / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "valu": {"achieved": round(valu_tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4), "flops_per_sample": round(d4_flops, 1),
+                     "note": "algorithmic flops of SURVEY §8(d4); the peak counts an FMA as 2 flops, which the "
+                             "parity contract (-ffp-contract=off) forbids, so 0.5 is the ceiling of this fraction"},
+            "note": ("the scene records are cache-resident or cache-friendly: most algorithmic bytes are served by the scalar "
+                     "cache / L1 / L2 / MALL (so `frac` can exceed 1), HBM sees `traffic`; the kernel is VALU-issue- and "
+                     "divergence-bound (DESIGN.md §5)"),
         }
         traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
         if os.path.exists(traffic_file):
