@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--force-exchange", action="store_true", help="run the exchange step even at N=1 (rehearsal of the N>1 path)")
+    ap.add_argument("--opts", default=os.environ.get("PTK_OPTS", ""), help="ptk_set_option pairs, k=v[,k=v...] (tuning experiments)")
+    ap.add_argument("--share-of", type=int, default=0, help="rehearsal: render only rank 0's tiles of an N-rank split on this one GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -134,7 +136,13 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        try:
+            # RCCL's own stream at high priority: the collective's workgroups get the wave slots that retiring
+            # trace_kernel waves free (the trace kernel of the next batch is already running, see step())
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), pg_options=opts)
+        except (AttributeError, TypeError):
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # ---- scene: synthesised through the reference's own formats (.obj + .pts) ---------------------
     tmp = tempfile.mkdtemp(prefix=f"bench_{args.config}_r{rank}_")
@@ -150,6 +158,8 @@ def main():
         pt.SetCameraAperture(0.0)               # exact pinhole through the API; the .pts carries F = 1e9
     pt.SetSeed(args.seed)
     pt.SetTile(rank, world)
+    if args.share_of > 1 and world == 1:
+        pt.SetTile(0, args.share_of)
     W, H = pt.GetResolution()
     D = pt.GetTraceDepth()
     pt.RenderFrames(1)                          # creates the frame buffers, primary-ray table; 1 spp
@@ -157,6 +167,10 @@ def main():
         print("bench.py: " + pt.LastError(), file=sys.stderr)
         sys.exit(3)
     ctx = pt.context()
+    for kv in args.opts.split(","):
+        if "=" in kv:
+            k, v = kv.split("=")
+            ctx.set_option(k, float(v))
     # the kernel renders into a torch-owned accumulator on torch's current stream, so the exchange
     # step (torch.distributed -> RCCL) is ordered behind the render without host synchronisation
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
@@ -216,10 +230,7 @@ def main():
         ntri_for_chunk = ctx.bvh_info()[2]
         # ptk's automatic samples per work item (ptk_api.hip run_passes)
         from pbrpathtracer_amd.distributed import owned_tile_count
-        per_item = spp * owned_tile_count(W, H, rank, world) * 4.0 / 49152.0
-        chunk, max_chunk = 4, (32 if ntri_for_chunk <= 16 else 16)
-        while chunk * 2 <= max_chunk and chunk * 2 <= per_item:
-            chunk *= 2
+        chunk = 8 if spp * owned_tile_count(W, H, rank, world) * 4.0 / 8.0 >= 49152.0 else 4
         chunk = min(chunk, spp)
         # counters over a few chunks of the whole frame, with the work-item size the timed launches used
         ctx.set_tile(0, 1)

@@ -125,6 +125,11 @@ int ptk_render(ptk_ctx* ctx, uint32_t first_sample, uint32_t spp_count, uint64_t
 /* the host-buffer hand-off of mOutImg (pathtracer.cpp:802-812, main.cpp:3026-3029):
  * W*H*3 bytes, RGB, rows bottom-up, tightly packed; waits for the stream */
 int ptk_resolve_rgb8(ptk_ctx* ctx, uint8_t* host_out);
+/* Page-locked host memory for the hand-off buffer (what `new GLubyte[w*h*3]` is in main.cpp:3435): a
+ * ptk_resolve_rgb8 into it is one DMA transfer instead of a staged copy.  Caller-owned, like texData:
+ * release with ptk_host_free before the context that allocated it is destroyed or after - either order. */
+void* ptk_host_alloc(size_t bytes);
+void  ptk_host_free(void* p);
 /* mTotalImg: W*H*3 floats, rows bottom-up; waits for the stream */
 int ptk_read_accum(ptk_ctx* ctx, float* host_out);
 int ptk_write_accum(ptk_ctx* ctx, const float* host_in, int samples);   /* resume from a saved accumulator */
@@ -146,8 +151,11 @@ int ptk_set_stream(ptk_ctx* ctx, void* hip_stream);
  * (ncclComm_t passed as void*); tiles a rank does not own are zero, so the sum is a gather */
 int ptk_gather_accum(ptk_ctx* ctx, void* rccl_comm, int root);
 
-/* tuning (none changes any result): "chunk" = samples per work item (default 0 = automatic: 16, or 32
- * for scenes of <= 16 triangles); "flat" = 0/1, scenes of <= 16 triangles skip the BVH walk and test
+/* tuning (none changes any result): "chunk" = samples per work item (default 0 = automatic: 8, or 4 when
+ * the rank's share of the frame is small); "max_batch" = queue slots a persistent wave pops at once (default 1); "persistent" = -1/0/1: waves pull
+ * work items from queues until none is left (1), or one item per wave (0); default -1 = by launch size; "generations" = persistent waves retire after 1/g of their share so that other
+ * streams' kernels (the exchange step) get wave slots mid-launch (default 0 = 1 on one GPU, 2 when tile-split: measured cost 0-2 %);
+ * "flat" = 0/1, scenes of <= 16 triangles skip the BVH walk and test
  * every triangle with scalar loads (default 1), "flat_shade_weight" / "flat_gen_weight" = its block-choice
  * weights in eighths (defaults 8 / 64); "pass_bytes" = HBM
  * budget of the sample buffer between the trace and accumulate kernels (default 4 GiB);

@@ -57,11 +57,22 @@ struct ptk_ctx {
     std::atomic<uint32_t> exit_req{ 0 };
     uint32_t* d_exit = nullptr;
     unsigned long long* d_stats = nullptr;
+    unsigned* d_queues = nullptr;                // item queues of trace_kernel's persistent waves
+    // live-quadrant list (which 8x8 quadrants of the owned tiles have pixels to trace) and what it was built for
+    unsigned long long* d_live_mask = nullptr;
+    unsigned* d_live_list = nullptr;             // [capacity] entries + 1 word: the count
+    int live_capacity = 0;
+    unsigned long long hit_generation = 0;       // bumped whenever the primary-hit cache is recomputed
+    struct LiveKey { int width, height, rank, world, cached; unsigned long long generation; } live_key = { 0, 0, -1, 0, -1, 0 };
+    int resident_waves = 4096;                   // one-wave workgroups the device holds at once (CUs x 16)
 
     // sample buffer between trace_kernel and accumulate_kernel (grown on demand, never shrunk)
     float4* d_samples = nullptr;
     size_t samples_bytes = 0;
-    int opt_chunk = 0;                           // samples per work item; 0 = automatic (16, or 32 in FLAT mode)
+    int opt_chunk = 0;                           // samples per work item; 0 = automatic (8, or 4 for small shares)
+    int opt_generations = 0;                     // 0 automatic: 1 on a single GPU, 2 when the frame is split over ranks
+    int opt_persistent = -1;                     // -1 automatic (by launch size), 0 one item per wave, 1 persistent waves
+    int opt_max_batch = 1;                       // slots a persistent wave pops from its queue at once; > 1 measured slower everywhere
     int opt_tri_thr = 4;                         // triangle arm of the walk runs when queued lanes >= tri_thr/8 x walking lanes
     int opt_shade_thr = 0, opt_gen_thr = 16;     // scheduling lambdas in eighths, see trace_kernel; 0 = by tree depth
     size_t opt_pass_bytes = (size_t)4 << 30;     // sample-buffer budget per pass
@@ -126,6 +137,20 @@ void frame_setup(ptk_ctx* c, PrimaryParams& pp)
     pp.primary = c->d_primary; pp.width = c->width; pp.height = c->height;
 }
 
+// on-image pixels of the tiles this rank owns (same tile -> rank map as the kernels)
+unsigned long long owned_pixels(const ptk_ctx* c)
+{
+    const int tiles_x = (c->width + PTK_TILE - 1) / PTK_TILE, tiles_y = (c->height + PTK_TILE - 1) / PTK_TILE;
+    unsigned long long n = 0;
+    for (int tile = c->rank; tile < tiles_x * tiles_y; tile += c->world)
+    {
+        const int ty = tile / tiles_x, tx = (tile % tiles_x + tiles_x - (3 * ty) % tiles_x) % tiles_x;
+        const int w = std::min(PTK_TILE, c->width - tx * PTK_TILE), h = std::min(PTK_TILE, c->height - ty * PTK_TILE);
+        n += (unsigned long long)w * h;
+    }
+    return n;
+}
+
 int ensure_primary(ptk_ctx* c)
 {
     if (!c->primary_dirty) return PTK_OK;
@@ -156,6 +181,9 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     p.shade_thr = c->opt_shade_thr > 0 ? c->opt_shade_thr : (c->bvh_depth <= 8 ? 200 : 40);
     p.gen_thr = c->opt_gen_thr;
     p.tri_thr = c->opt_tri_thr;
+    p.max_batch = c->opt_max_batch;
+    p.persistent = c->opt_persistent;
+    p.generations = c->opt_generations > 0 ? c->opt_generations : (c->world > 1 ? 2 : 1);
     p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.stats = c->d_stats;
     p.num_nodes = c->num_nodes; p.num_lights = c->num_lights;
     p.flat_count = (c->opt_flat && c->num_tris <= 16) ? c->num_tris : 0;
@@ -194,26 +222,44 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
             launch_primary_hits(p, c->d_primary_hit, c->stream);
             HIPCHK(c, hipGetLastError());
             c->primary_hit_dirty = false;
+            c->hit_generation++;
         }
         p.primary_hit = c->d_primary_hit;
     }
     const int tiles = owned_tiles(p);
     c->last_passes = 0; c->last_launches = 0;
     if (tiles == 0) return PTK_OK;
+    {
+        // the list of quadrants with live pixels: rebuilt when the frame, the tile ownership or the cached camera hits change
+        const int subtiles = tiles * 4;
+        if (subtiles > c->live_capacity)
+        {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            dfree(c->d_live_mask); dfree(c->d_live_list); c->live_capacity = 0;
+            HIPCHK(c, hipMalloc(&c->d_live_mask, (size_t)subtiles * sizeof(unsigned long long)));
+            HIPCHK(c, hipMalloc(&c->d_live_list, ((size_t)subtiles + 1) * sizeof(unsigned)));
+            c->live_capacity = subtiles;
+            c->live_key.rank = -1;
+        }
+        const ptk_ctx::LiveKey key = { c->width, c->height, c->rank, c->world, p.primary_hit ? 1 : 0, p.primary_hit ? c->hit_generation : 0ull };
+        const ptk_ctx::LiveKey& o = c->live_key;
+        if (key.width != o.width || key.height != o.height || key.rank != o.rank || key.world != o.world || key.cached != o.cached ||
+            key.generation != o.generation)
+        {
+            launch_live_list(p, subtiles, c->d_live_mask, c->d_live_list, c->d_live_list + c->live_capacity, c->stream);
+            HIPCHK(c, hipGetLastError());
+            c->live_key = key;
+        }
+        p.live_mask = c->d_live_mask; p.live_list = c->d_live_list; p.live_count = c->d_live_list + c->live_capacity;
+    }
     const size_t per_sample = (size_t)tiles * 4 * 64 * sizeof(float4);
-    // Samples per work item: longer chunks amortise the end-of-chunk tail (the FLAT walk is short and
-    // uniform, so it affords 32; the BVH walk 16), but a launch must still consist of many more work
-    // items than the 4096 wave slots of the chip or its duration degenerates to that of its slowest
-    // item - which is what a rank of an 8-GPU job would see with its 1/8 of the tiles.  Aim for >= 48 k
-    // items (measured optimum at 1/4 and 1/8 of the C2 frame), never below 4 samples per item.
+    // Samples per work item.  The waves are persistent and lanes take units from item after item, so short items
+    // cost no SIMD utilisation any more; what they buy is balance at the end of the launch (the last items are
+    // the tail) and concurrency on the same pixels.  8 is the measured optimum for whole frames (C2, C4); a rank
+    // that owns 1/4 or 1/8 of the tiles does better with 4.  Each item costs one queue pop (~2 us of latency).
     int chunk_opt = c->opt_chunk;
     if (chunk_opt <= 0)
-    {
-        const int max_chunk = p.flat_count > 0 ? 32 : 16;
-        const double per_item = (double)spp * (double)tiles * 4.0 / 49152.0;
-        chunk_opt = 4;
-        while (chunk_opt * 2 <= max_chunk && chunk_opt * 2 <= per_item) chunk_opt *= 2;
-    }
+        chunk_opt = (double)spp * (double)tiles * 4.0 / 8.0 >= 49152.0 ? 8 : 4;
     uint32_t max_pass = (uint32_t)std::max<size_t>(1, c->opt_pass_bytes / per_sample);
     if (max_pass > (uint32_t)chunk_opt) max_pass -= max_pass % (uint32_t)chunk_opt;
     uint32_t done = 0;
@@ -239,7 +285,8 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         p.num_items = (int)items;
         const int pi = c->last_passes < ptk_ctx::kMaxTimedPasses ? c->last_passes : -1;
         if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][0], c->stream));
-        launch_trace(p, (int)items, c->stream, stats);
+        p.queues = c->d_queues;
+        launch_trace(p, tiles * 4, c->resident_waves, c->stream, stats);
         HIPCHK(c, hipGetLastError());
         if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][1], c->stream));
         launch_accumulate(p, tiles, c->stream);
@@ -269,8 +316,14 @@ int ptk_create(ptk_ctx** out, int device_ordinal)
     c->device = device_ordinal;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PTK_ERR_HIP; }
     c->own_stream = true;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0)
+            c->resident_waves = cus * 16;        // 4 SIMDs x 4 waves of trace_kernel (112-114 VGPRs) per CU
+    }
     if (hipMalloc(&c->d_exit, sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_exit, 0, sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&c->d_stats, 16 * sizeof(unsigned long long)) != hipSuccess)
+        hipMalloc(&c->d_stats, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&c->d_queues, (8 * PTK_QUEUE_STRIDE + QG_WORDS) * sizeof(unsigned)) != hipSuccess)
     {
         ptk_destroy(c);
         return PTK_ERR_HIP;
@@ -289,7 +342,8 @@ void ptk_destroy(ptk_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_mats); dfree(c->d_lights);
     dfree(c->d_texinfo); dfree(c->d_texels); dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_accum); dfree(c->d_rgb8);
-    dfree(c->d_exit); dfree(c->d_stats); dfree(c->d_samples);
+    dfree(c->d_exit); dfree(c->d_stats); dfree(c->d_queues); dfree(c->d_samples);
+    dfree(c->d_live_mask); dfree(c->d_live_list);
     for (int i = 0; i < ptk_ctx::kMaxTimedPasses; i++)
         for (int k = 0; k < 3; k++)
             if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
@@ -576,7 +630,7 @@ int ptk_collect_stats(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uin
     (void)hipFree(scratch); (void)hipFree(scratch8);
     if (rc != PTK_OK) return rc;
     if (e != hipSuccess) return fail(c, PTK_ERR_HIP, hipGetErrorString(e));
-    out->samples = h[0]; out->rays = h[1]; out->shadow_rays = h[2]; out->node_visits = h[3];
+    out->samples = owned_pixels(c) * (unsigned long long)spp_count; out->rays = h[1]; out->shadow_rays = h[2]; out->node_visits = h[3];
     out->tri_tests = h[4]; out->hits_shaded = h[5]; out->tex_fetches = h[6];
     out->walk_wave_iters = h[7]; out->walk_lane_iters = h[8]; out->shade_wave_execs = h[9]; out->shade_lanes = h[10];
     out->gen_wave_execs = h[11]; out->gen_lanes = h[12];
@@ -593,6 +647,14 @@ int ptk_resolve_rgb8(ptk_ctx* c, uint8_t* host_out)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PTK_OK;
 }
+
+void* ptk_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void ptk_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int ptk_read_accum(ptk_ctx* c, float* host_out)
 {
@@ -715,6 +777,24 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     {
         if (!(value >= 0 && value <= 4096)) return fail(c, PTK_ERR_BAD_ARG, "threshold (lambda in eighths) must be in [0, 4096]");
         (name[0] == 's' ? c->opt_shade_thr : c->opt_gen_thr) = (int)value;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "generations"))
+    {
+        if (!(value >= 0 && value <= 64)) return fail(c, PTK_ERR_BAD_ARG, "generations must be in [0, 64] (0 = automatic)");
+        c->opt_generations = (int)value;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "persistent"))
+    {
+        if (!(value >= -1 && value <= 1)) return fail(c, PTK_ERR_BAD_ARG, "persistent must be -1 (automatic), 0 or 1");
+        c->opt_persistent = (int)value;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "max_batch"))
+    {
+        if (!(value >= 1 && value <= 64)) return fail(c, PTK_ERR_BAD_ARG, "max_batch must be in [1, 64]");
+        c->opt_max_batch = (int)value;
         return PTK_OK;
     }
     if (!std::strcmp(name, "tri_threshold"))

@@ -44,10 +44,21 @@ constexpr int LIGHT_F4 = 4;
 // The accumulate kernel folds them into the float accumulator strictly in sample order, which keeps
 // the reference's `mTotalImg[px] += color` once per RenderFrame() semantics (pathtracer.cpp:798-800)
 // while the tracing itself is parallel over pixels AND samples.
+#define PTK_QUEUE_STRIDE 32     // one queue counter per 128-B line
+// words of the launch geometry that follows the 8 counters in the queue block
+enum { QG_NUM_CHUNKS = 0, QG_WORLD, QG_RANK, QG_TILES_X, QG_CHUNK, QG_SPP, QG_SLOTS, QG_LIVE_COUNT, QG_QUOTA, QG_WORDS = 16 };
+
 struct RenderParams {
     float4* samples;
     int chunk, num_chunks;      // samples per work item, work items per 8x8 tile
     int num_items;              // owned tiles * 4 * num_chunks
+    int max_batch;              // most slots a wave pops from a queue at once
+    int generations;            // persistent launches: waves retire after 1/generations of their share (1 = never)
+    int persistent;             // 1: resident waves pull items from the queues; 0: one item per wave, named by blockIdx
+    const unsigned long long* live_mask;   // per owned quadrant: its pixels that need tracing
+    const unsigned* live_list;  // quadrants with a non-zero mask, ascending; *live_count entries
+    const unsigned* live_count;
+    unsigned* queues;           // queue block: 8 slot counters PTK_QUEUE_STRIDE words apart + QG_WORDS of launch geometry
     int shade_thr, gen_thr;     // scheduling lambdas (eighths): cost of the shade / gen block in walk steps
     int tri_thr;                // triangle arm runs when lanes with a queued triangle >= tri_thr/8 x lanes with a node
     const float4* nodes;
@@ -97,7 +108,8 @@ struct ProbeParams {
     int n, num_nodes;
 };
 
-void launch_trace(const RenderParams& p, int num_items, hipStream_t stream, bool stats);
+void launch_trace(const RenderParams& p, int num_subtiles, int resident_waves, hipStream_t stream, bool stats);
+void launch_live_list(const RenderParams& p, int num_subtiles, unsigned long long* mask, unsigned* list, unsigned* count, hipStream_t stream);
 void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t stream);
 void launch_primary(const PrimaryParams& p, hipStream_t stream);
 void launch_primary_hits(const RenderParams& p, float4* out, hipStream_t stream);

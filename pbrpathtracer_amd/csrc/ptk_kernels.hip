@@ -376,53 +376,138 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     const int tid = threadIdx.x;
     int* stack = lds_stack + tid;
     const int lane = tid & 63;
-    // work item of this WAVE: (owned 16x16 tile, 8x8 quadrant, chunk of samples)
-    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each
-    // with its own L2.  Hand every XCD whole 16x16 tiles (run = the 4 x num_chunks work items of a tile), tile
-    // by tile round-robin, so the waves that trace the same pixels - the same BVH nodes and triangles - share
-    // an L2 instead of being sprayed over all eight.  (Runs, not one contiguous eighth of the frame per XCD:
-    // the dispatcher deals blocks in order, so an XCD holding the cheap part of the image would stall the rest.)
-    static_assert(PTK_TRACE_BLOCK == 64, "the XCD mapping below assumes one wave per workgroup");
-    const int run = 4 * P.num_chunks;
-    const int b = (int)blockIdx.x;
-    const int slot = b >> 3;                                           // b-th wave dealt to XCD (b & 7)
-    const int item = ((slot / run) * 8 + (b & 7)) * run + slot % run;
-    const int subtile = item / P.num_chunks, chunk_id = item - subtile * P.num_chunks;
-    const int owned = subtile >> 2, quad = subtile & 3;
-    const int tile = owned * P.world + P.rank;
-    if (tile >= P.num_tiles || item >= P.num_items) return;
-    // rows are rotated by 3 tiles each so that a rank's tiles form diagonals, not columns (load balance)
-    const int ty = tile / P.tiles_x, tx = (tile % P.tiles_x + P.tiles_x - (3 * ty) % P.tiles_x) % P.tiles_x;
-    const int px = tx * PTK_TILE + (quad & 1) * 8 + (lane & 7);
-    const int py = ty * PTK_TILE + (quad >> 1) * 8 + (lane >> 3);     // row from the top (pathtracer.cpp:777)
-    const bool valid = px < P.width && py < P.height;
-    const uint32_t s_begin = (uint32_t)chunk_id * (uint32_t)P.chunk;
-    const uint32_t s_count = min((uint32_t)P.chunk, P.spp - s_begin);  // host guarantees s_begin < spp
-    const size_t out_base = ((size_t)item * P.chunk) * 64;             // sample s of tile pixel q: P.samples[out_base + s * 64 + q]
-
-    // Work units of this item = (live pixel of the 8x8 tile, sample of the chunk), sample-major.  They are
-    // dealt to whichever lane needs work next, NOT pinned pixel-to-lane: every lane of the wave keeps
-    // tracing until the item's units are used up, so lanes finish within one path of each other
-    // (a pixel-per-lane mapping idles the wave while its unluckiest pixel finishes its 16-32 samples,
-    // and idles the lanes of off-image or sky pixels altogether).
-    __shared__ unsigned char lds_pixel_of_rank[PTK_TRACE_BLOCK];
-    // a pixel whose cached primary ray misses is black for every sample (pathtracer.cpp:550): nothing is
-    // traced or stored for it, and accumulate_kernel skips its (all-zero) samples
-    const bool black = P.primary_hit && valid && __float_as_int(P.primary_hit[(size_t)py * P.width + px].x) == PTK_NOHIT;
-    const bool live_pixel = valid && !black && s_count > 0;
-    const unsigned long long live_mask = __ballot(live_pixel);
-    const uint32_t n_live_px = (uint32_t)__popcll(live_mask);
-    if (n_live_px == 0)
+    // ---- work distribution -------------------------------------------------------------------------
+    // Work item = (owned 16x16 tile, 8x8 quadrant, chunk of samples); its work UNITS = (live pixel of the
+    // quadrant, sample of the chunk), sample-major.  Units are dealt to whichever lane needs work next, NOT
+    // pinned pixel-to-lane, and the waves are PERSISTENT: a wave that has dealt the last unit of its item
+    // takes the next item from a queue while its other lanes are still finishing paths of the previous one,
+    // so all 64 lanes keep tracing until the whole launch runs dry (a lane's state carries its own pixel,
+    // sample and output slot).  A pixel-per-lane mapping idled the wave while its unluckiest pixel finished
+    // its samples, and a wave per item left a tail at the end of every item.
+    //
+    // XCD-aware queues: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each
+    // with its own L2.  There is one queue per XCD group, holding whole 16x16 tiles (runs of 4 x num_chunks
+    // items) tile by tile round-robin, so the waves that trace the same pixels - the same BVH nodes and
+    // triangles - share an L2; a group whose queue is empty steals from the others.  (One contiguous eighth
+    // of the frame per XCD was 2x slower when the dispatcher dealt the items: cheap and dear regions.)
+    static_assert(PTK_TRACE_BLOCK == 64, "one wave per workgroup");
+    __shared__ unsigned char lds_pixel_of_rank[64];
+    // the current item: read only when units are dealt, so it lives in LDS, not in registers the hot loops want
+    enum { IT_NLIVE = 0, IT_X0, IT_Y0, IT_SBEGIN, IT_OUTBASE,
+           IT_STEAL,                // queues (group + steal) & 7 ... are the ones not yet seen empty; 8 = none left
+           IT_LO, IT_HI, IT_G,      // slots [lo, hi) of queue g this wave has popped and not yet used
+           IT_REMAIN,               // slots that queue had left after that pop (sizes the next batch)
+           IT_TAKEN,                // items this wave has traced so far (against the launch's per-wave quota, if any)
+           IT_WORDS };
+    __shared__ uint32_t lds_item[IT_WORDS];
+    if (lane == 0)
     {
-        if (STATS) atomicAdd(&P.stats[0], (unsigned long long)(valid ? s_count : 0));
-        return;                     // whole wave; the workgroup is this one wave
+        // small launches (P.persistent == 0: few items per wave slot) run one item per wave, named by blockIdx,
+        // with no queue traffic at all - the hardware dispatcher balances those better than 4096 waves
+        // contending for eight counters could
+        lds_item[IT_STEAL] = P.persistent ? 0u : 8u;
+        lds_item[IT_LO] = P.persistent ? 0u : (uint32_t)blockIdx.x >> 3;
+        lds_item[IT_HI] = P.persistent ? 0u : ((uint32_t)blockIdx.x >> 3) + 1u;
+        lds_item[IT_G] = (uint32_t)blockIdx.x & 7u;
+        lds_item[IT_REMAIN] = 0xffffffffu;      // "unknown": the first pop is sized from the whole queue
+        lds_item[IT_TAKEN] = 0u;
     }
-    const uint32_t total_units = n_live_px * s_count;
-    if (live_pixel) lds_pixel_of_rank[(tid & ~63) + __popcll(live_mask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
     __syncthreads();
-    uint32_t next_unit = 0;         // wave-uniform
-    int q = 0;                      // tile pixel (0..63) of the path this lane is tracing
-    uint32_t pix = 0;               // its row-major pixel index from the top
+    uint32_t total_units = 0, next_unit = 0;    // wave-uniform
+    // per-lane: the unit this lane is tracing
+    uint32_t pix = 0;               // row-major pixel index from the top
+    uint32_t sample_abs = 0;        // sample index inside this launch (chunk start + index in the chunk)
+    uint32_t out_idx = 0;           // its slot in the sample buffer
+
+    // takes the next non-empty item (-> lds_item, lds_pixel_of_rank); returns its unit count, 0 when every queue is empty
+    auto acquire_item = [&]() -> uint32_t {
+        // the launch geometry is re-read from the queue block (one coalesced load, fields broadcast with
+        // v_readlane) instead of living in SGPRs across the hot loops, where it forced spills
+        const int geo = ((const int*)(P.queues + 8 * PTK_QUEUE_STRIDE))[lane & 15];
+        const int num_chunks = __builtin_amdgcn_readlane(geo, QG_NUM_CHUNKS), world = __builtin_amdgcn_readlane(geo, QG_WORLD);
+        const int rank = __builtin_amdgcn_readlane(geo, QG_RANK);
+        const int tiles_x = __builtin_amdgcn_readlane(geo, QG_TILES_X), chunk = __builtin_amdgcn_readlane(geo, QG_CHUNK);
+        const uint32_t spp = (uint32_t)__builtin_amdgcn_readlane(geo, QG_SPP);
+        const int slots_per_queue = __builtin_amdgcn_readlane(geo, QG_SLOTS), live_count = __builtin_amdgcn_readlane(geo, QG_LIVE_COUNT);
+        // multi-GPU runs launch several generations of waves, each retiring after its quota of items, so that the
+        // kernels of the exchange step (RCCL, on another stream) find free wave slots while this kernel is running
+        const uint32_t quota = (uint32_t)__builtin_amdgcn_readlane(geo, QG_QUOTA);
+        const int my_group = (int)blockIdx.x & 7;
+        int steal = (int)lds_item[IT_STEAL];
+        int lo = (int)lds_item[IT_LO], hi = (int)lds_item[IT_HI], cur_g = (int)lds_item[IT_G];
+        uint32_t remain = lds_item[IT_REMAIN];
+        const int pullers = max(1, (int)gridDim.x >> 3);           // waves that share one queue
+        if (quota != 0u && lds_item[IT_TAKEN] >= quota && lo >= hi) steal = 8;
+        for (;;)
+        {
+            while (lo >= hi && steal < 8)
+            {
+                // pop the next slot(s).  P.max_batch > 1 pops guided batches (a share of what is left per puller,
+                // shrinking towards the end); measured slower on every config - consecutive slots are the chunks of
+                // ONE quadrant, which are better traced by several waves at the same time - so the default is 1
+                const int g = (my_group + steal) & 7;
+                // (what the queue had left after this wave's previous pop has roughly halved since: the other
+                // pullers popped meanwhile)
+                const uint32_t left = g == cur_g && remain != 0xffffffffu ? remain / 2u : (uint32_t)slots_per_queue;
+                const int want = max(1, min(P.max_batch, (int)(left / (4u * (uint32_t)pullers))));
+                int old = 0;
+                if (lane == 0) old = (int)atomicAdd(&P.queues[g * PTK_QUEUE_STRIDE], (unsigned)want);
+                old = __builtin_amdgcn_readfirstlane(old);
+                if (old < slots_per_queue)
+                {
+                    lo = old; hi = min(slots_per_queue, old + want); cur_g = g;
+                    remain = (uint32_t)(slots_per_queue - hi);
+                    break;
+                }
+                // this queue is empty: look at all eight counters at once (one load) and move on to the next
+                // one that still has items, instead of finding each of them empty with an atomic of its own
+                unsigned seen = ~0u;
+                if (lane < 8) seen = __hip_atomic_load(&P.queues[((my_group + lane) & 7) * PTK_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned avail = (unsigned)__ballot(seen < (unsigned)slots_per_queue) & 0xffu & (0xffu << (steal + 1));
+                steal = avail ? __builtin_ctz(avail) : 8;
+                if (steal < 8)
+                {
+                    // size the first pop from the victim by what it was just seen to have left
+                    cur_g = (my_group + steal) & 7;
+                    remain = 2u * ((uint32_t)slots_per_queue - (uint32_t)__builtin_amdgcn_readlane((int)seen, steal));
+                }
+            }
+            if (lo >= hi) break;
+            const int slot = lo++;
+            if (slot >= slots_per_queue) continue;                             // (one-item-per-wave mode: surplus block)
+            // slot -> (entry of the live list, chunk): a queue holds runs of four consecutive entries - the
+            // quadrants of one tile, as a rule - so that tile is traced within one XCD
+            const int e = slot / num_chunks, chunk_id = slot - e * num_chunks;
+            const int v = ((e >> 2) * 8 + cur_g) * 4 + (e & 3);
+            if (v >= live_count) continue;                                     // padding of the last runs
+            const int subtile = (int)P.live_list[v];                           // (owned tile) * 4 + quadrant
+            const unsigned long long live_mask = P.live_mask[subtile];         // its pixels that need tracing
+            const int item = subtile * num_chunks + chunk_id;
+            const int owned = subtile >> 2, quad = subtile & 3;
+            const int tile = owned * world + rank;
+            // rows are rotated by 3 tiles each so that a rank's tiles form diagonals, not columns (load balance)
+            const int ty = tile / tiles_x, tx = (tile % tiles_x + tiles_x - (3 * ty) % tiles_x) % tiles_x;
+            const int x0 = tx * PTK_TILE + (quad & 1) * 8, y0 = ty * PTK_TILE + (quad >> 1) * 8;
+            const uint32_t s_begin = (uint32_t)chunk_id * (uint32_t)chunk;
+            const uint32_t s_count = min((uint32_t)chunk, spp - s_begin);      // host guarantees s_begin < spp
+            const uint32_t n_live = (uint32_t)__popcll(live_mask);
+            if (n_live == 0) continue;
+            __syncthreads();                    // every lane is done with the previous item's table
+            if ((live_mask >> lane) & 1ull) lds_pixel_of_rank[__popcll(live_mask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+            if (lane == 0)
+            {
+                lds_item[IT_NLIVE] = n_live; lds_item[IT_X0] = (uint32_t)x0; lds_item[IT_Y0] = (uint32_t)y0;
+                lds_item[IT_SBEGIN] = s_begin; lds_item[IT_STEAL] = (uint32_t)steal; lds_item[IT_TAKEN] += 1u;
+                lds_item[IT_LO] = (uint32_t)lo; lds_item[IT_HI] = (uint32_t)hi; lds_item[IT_G] = (uint32_t)cur_g; lds_item[IT_REMAIN] = remain;
+                lds_item[IT_OUTBASE] = (uint32_t)item * (uint32_t)chunk * 64u;   // sample s of quadrant pixel q: P.samples[base + s * 64 + q]
+            }
+            __syncthreads();
+            return n_live * s_count;
+        }
+        if (lane == 0) { lds_item[IT_STEAL] = 8u; lds_item[IT_LO] = lds_item[IT_HI] = 0u; }
+        __syncthreads();
+        return 0u;
+    };
 
     const v3 camPos0 = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
     const v3 camRight = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
@@ -444,13 +529,12 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     int depth = 0, iter = 0;
     bool inside = false;
     uint32_t ray = 0;
-    uint32_t sample = 0;            // index inside this chunk
     int st = ST_NEED;               // every lane works, whatever its own pixel is
 
     // a finished path: its radiance goes to the sample buffer, the lane moves to its next sample
 #define PTK_FINISH_PATH()                                                                         \
     do {                                                                                          \
-        P.samples[out_base + (size_t)sample * 64 + q] = make_float4(L.x, L.y, L.z, 0.0f);          \
+        P.samples[out_idx] = make_float4(L.x, L.y, L.z, 0.0f);                                    \
         st = ST_NEED;                                                                             \
     } while (0)
 
@@ -476,26 +560,30 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     int debt_shade = 0, debt_gen = 0;      // wave-uniform: lane-iterations wasted by parked lanes
     for (;;)
     {
+        // deal the next work units to the lanes that need one (wave-uniform code)
         {
-            // deal the next work units to the lanes that need one (wave-uniform code)
-            const unsigned long long m_need = __ballot(st == ST_NEED);
-            if (m_need)
+            unsigned long long m_need = __ballot(st == ST_NEED);
+            while (m_need)
             {
-                if (st == ST_NEED)
+                if (next_unit >= total_units)
                 {
-                    const uint32_t u = next_unit + (uint32_t)__popcll(m_need & ((1ull << lane) - 1ull));
-                    if (u < total_units)
-                    {
-                        sample = u / n_live_px;
-                        q = lds_pixel_of_rank[(tid & ~63) + (u - sample * n_live_px)];
-                        const int qx = tx * PTK_TILE + (quad & 1) * 8 + (q & 7);
-                        const int qy = ty * PTK_TILE + (quad >> 1) * 8 + (q >> 3);   // row from the top (pathtracer.cpp:777)
-                        pix = (uint32_t)(qy * P.width + qx);
-                        st = ST_GEN;
-                    }
-                    else st = ST_DONE;
+                    next_unit = 0;
+                    total_units = (lds_item[IT_STEAL] < 8u || lds_item[IT_LO] < lds_item[IT_HI]) ? acquire_item() : 0u;
+                    if (total_units == 0) { if (st == ST_NEED) st = ST_DONE; break; }
                 }
-                next_unit += (uint32_t)__popcll(m_need);
+                const uint32_t n_live = lds_item[IT_NLIVE];
+                const uint32_t u = next_unit + (uint32_t)__popcll(m_need & ((1ull << lane) - 1ull));
+                if (st == ST_NEED && u < total_units)
+                {
+                    const uint32_t s_in_chunk = u / n_live;
+                    const uint32_t q = lds_pixel_of_rank[u - s_in_chunk * n_live];
+                    pix = (lds_item[IT_Y0] + (q >> 3)) * (uint32_t)P.width + lds_item[IT_X0] + (q & 7u);
+                    sample_abs = lds_item[IT_SBEGIN] + s_in_chunk;
+                    out_idx = lds_item[IT_OUTBASE] + s_in_chunk * 64u + q;
+                    st = ST_GEN;
+                }
+                next_unit = min(total_units, next_unit + (uint32_t)__popcll(m_need));
+                m_need = __ballot(st == ST_NEED);
             }
         }
         const unsigned long long m_trav = __ballot(st == ST_TRAV);
@@ -806,7 +894,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
                 // ---- camera ray with thin-lens DOF, pathtracer.cpp:785-791 + SampleCircle :734-739 ----
                 const uint32_t pkey = pixel_key(P.seed_lo, P.seed_hi, pix);
                 rng.inc = (hash32(pkey ^ 0x9E3779B9u) << 1) | 1u;
-                rng.state = hash32(P.first_sample + s_begin + sample + pkey);
+                rng.state = hash32(P.first_sample + sample_abs + pkey);
                 rng.key = rng.state;
                 // per-pixel constants are re-read here (L1/L2 hits) instead of living in registers
                 const float4 d0 = P.primary[pix];
@@ -847,7 +935,6 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
 
     if (STATS)
     {
-        atomicAdd(&P.stats[0], (unsigned long long)(valid ? s_count : 0));
         atomicAdd(&P.stats[1], (unsigned long long)cnt.rays);
         atomicAdd(&P.stats[2], (unsigned long long)cnt.shadow);
         atomicAdd(&P.stats[3], (unsigned long long)cnt.nodes);
@@ -971,13 +1058,92 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_hits_kernel(const ProbeParams
     P.tuv[i * 3] = hit ? W.best.t : 0.0f; P.tuv[i * 3 + 1] = hit ? W.best.u : 0.0f; P.tuv[i * 3 + 2] = hit ? W.best.v : 0.0f;
 }
 
-void launch_trace(const RenderParams& p, int num_items, hipStream_t stream, bool stats)
+struct QueueGeometry { int w[QG_WORDS]; };
+__global__ void queue_init_kernel(unsigned* block, const QueueGeometry geo, const unsigned* live_count)
 {
-    if (num_items <= 0) return;
-    int blocks = (num_items + (PTK_TRACE_BLOCK / 64) - 1) / (PTK_TRACE_BLOCK / 64);
-    // trace_kernel deals whole tiles (runs of 4 * num_chunks items) to the 8 XCDs: pad to 8 runs
-    const int group = 8 * 4 * p.num_chunks;
-    blocks = (num_items + group - 1) / group * group / (PTK_TRACE_BLOCK / 64);
+    const int t = threadIdx.x;
+    if (t < 8) block[t * PTK_QUEUE_STRIDE] = 0u;
+    int w = t < QG_WORDS ? geo.w[t] : 0;
+    const int n = (int)*live_count;
+    if (t == QG_LIVE_COUNT) w = n;
+    if (t == QG_SLOTS) w = (n + 31) / 32 * 4 * geo.w[QG_NUM_CHUNKS];      // per queue: runs of 4 entries, 8 queues
+    if (t == QG_QUOTA && w > 0) w = (n * geo.w[QG_NUM_CHUNKS] + w - 1) / w;  // in: blocks of a multi-generation launch; out: items per block
+    if (t < QG_WORDS) ((int*)(block + 8 * PTK_QUEUE_STRIDE))[t] = w;
+}
+
+// Which pixels of every owned 8x8 quadrant need tracing: on the image, and - when the camera ray's closest hit is
+// cached - not a miss (pathtracer.cpp:550: such a pixel is black for every sample).  One wave per quadrant.
+__global__ __launch_bounds__(PTK_BLOCK) void live_mask_kernel(const RenderParams P, unsigned long long* mask, int num_subtiles)
+{
+    const int subtile = blockIdx.x * (PTK_BLOCK / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (subtile >= num_subtiles) return;
+    const int owned = subtile >> 2, quad = subtile & 3;
+    const int tile = owned * P.world + P.rank;
+    bool live = false;
+    if (tile < P.num_tiles)
+    {
+        const int ty = tile / P.tiles_x, tx = (tile % P.tiles_x + P.tiles_x - (3 * ty) % P.tiles_x) % P.tiles_x;
+        const int px = tx * PTK_TILE + (quad & 1) * 8 + (lane & 7), py = ty * PTK_TILE + (quad >> 1) * 8 + (lane >> 3);
+        live = px < P.width && py < P.height;
+        if (live && P.primary_hit) live = __float_as_int(P.primary_hit[(size_t)py * P.width + px].x) != PTK_NOHIT;
+    }
+    const unsigned long long m = __ballot(live);
+    if (lane == 0) mask[subtile] = m;
+}
+
+// Ordered list of the quadrants that have live pixels (single workgroup: a few hundred thousand quadrants at most).
+__global__ __launch_bounds__(1024) void live_compact_kernel(const unsigned long long* mask, int num_subtiles, unsigned* list, unsigned* count)
+{
+    __shared__ unsigned wave_total[16];
+    __shared__ unsigned base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int s0 = 0; s0 < num_subtiles; s0 += 1024)
+    {
+        const int sidx = s0 + t;
+        const bool live = sidx < num_subtiles && mask[sidx] != 0ull;
+        const unsigned long long b = __ballot(live);
+        if (lane == 0) wave_total[wave] = (unsigned)__popcll(b);
+        __syncthreads();
+        unsigned before = base;
+        for (int w = 0; w < wave; w++) before += wave_total[w];
+        if (live) list[before + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = (unsigned)sidx;
+        __syncthreads();
+        if (t == 0) { unsigned sum = 0; for (int w = 0; w < 16; w++) sum += wave_total[w]; base += sum; }
+        __syncthreads();
+    }
+    if (t == 0) *count = base;
+}
+
+void launch_live_list(const RenderParams& p, int num_subtiles, unsigned long long* mask, unsigned* list, unsigned* count, hipStream_t stream)
+{
+    if (num_subtiles <= 0) return;
+    const int per_block = PTK_BLOCK / 64;
+    hipLaunchKernelGGL(live_mask_kernel, dim3((num_subtiles + per_block - 1) / per_block), dim3(PTK_BLOCK), 0, stream, p, mask, num_subtiles);
+    hipLaunchKernelGGL(live_compact_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)mask, num_subtiles, list, count);
+}
+
+void launch_trace(const RenderParams& p0, int num_subtiles, int resident_waves, hipStream_t stream, bool stats)
+{
+    if (num_subtiles <= 0) return;
+    RenderParams p = p0;
+    // the items = (entry of the live list, chunk) go into 8 queues (one per XCD group) in runs of four entries; the
+    // host only knows an upper bound of the list's length (every quadrant live), the device the real one
+    const int padded = (num_subtiles + 31) / 32 * 32 * p.num_chunks;
+    // queue block = 8 zeroed slot counters (one per 128-B line) followed by the launch geometry the item set-up reads;
+    // written by a one-wave kernel from its own arguments (stream-ordered, nothing for the host to wait on)
+    QueueGeometry geo = {};
+    geo.w[QG_NUM_CHUNKS] = p.num_chunks; geo.w[QG_WORLD] = p.world; geo.w[QG_RANK] = p.rank;
+    geo.w[QG_TILES_X] = p.tiles_x; geo.w[QG_CHUNK] = p.chunk; geo.w[QG_SPP] = (int)p.spp;
+    // big launches: persistent waves, as many one-wave workgroups as the chip holds at once, each pulling items until
+    // none is left; small ones: a wave per (possible) item, the dispatcher balances those better
+    if (p.persistent < 0) p.persistent = padded > 4 * resident_waves ? 1 : 0;
+    const int generations = p.persistent ? std::max(1, std::min(p.generations, padded / resident_waves)) : 1;
+    const int blocks = p.persistent ? resident_waves * generations : padded;
+    geo.w[QG_QUOTA] = generations > 1 ? blocks : 0;
+    hipLaunchKernelGGL(queue_init_kernel, dim3(1), dim3(64), 0, stream, p.queues, geo, p.live_count);
     const bool flat = p.flat_count > 0;
     if (stats && flat) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
     else if (stats) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);

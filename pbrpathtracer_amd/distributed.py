@@ -58,7 +58,8 @@ class AccumulatorExchange:
         self.result = torch.empty_like(local)
         self.cuda = local.is_cuda
         if self.cuda:
-            self.side = torch.cuda.Stream(device=local.device)
+            # high priority: its copy and the collective take wave slots ahead of the render stream's queued workgroups
+            self.side = torch.cuda.Stream(device=local.device, priority=-1)
             self.rendered = torch.cuda.Event()
             self.copied = torch.cuda.Event()
 

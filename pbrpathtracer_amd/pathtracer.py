@@ -91,6 +91,24 @@ def _f3(v):
     return np.ascontiguousarray(v, dtype=np.float32).reshape(3)
 
 
+class _PinnedBuffer:
+    """Owner of one ptk_host_alloc block, exposed to numpy through the array interface."""
+
+    def __init__(self, shape):
+        from . import ptk as _ptk
+        self._L = _ptk.load()
+        n = int(np.prod(shape))
+        self._p = self._L.ptk_host_alloc(n)
+        if not self._p:
+            raise MemoryError("ptk_host_alloc failed (no HIP device?)")
+        self.__array_interface__ = {"shape": tuple(shape), "typestr": "|u1", "data": (self._p, False), "version": 3}
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self._L.ptk_host_free(self._p)
+            self._p = None
+
+
 class PathTracer:
     """The reference's PathTracer API (method names kept verbatim) + the marked extensions."""
 
@@ -147,6 +165,12 @@ class PathTracer:
             assert out.dtype == np.uint8 and out.flags.c_contiguous
         self._out = out
         self.L.pth_set_out_image(self.h, out.ctypes.data if out is not None else None)
+
+    def AllocOutImage(self) -> np.ndarray:
+        """A page-locked W*H*3 uint8 hand-off buffer (ptk_host_alloc) for SetOutImage: RenderFrame()'s copy into
+        it is a single DMA transfer.  Freed when the returned array (and its views) are garbage-collected."""
+        w, h = self.GetResolution()
+        return np.asarray(_PinnedBuffer((h, w, 3)))
 
     def SetResolution(self, res: Sequence[int]): self.L.pth_set_resolution(self.h, int(res[0]), int(res[1]))
 

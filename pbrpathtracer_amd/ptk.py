@@ -62,7 +62,7 @@ SYMBOLS = [
     "ptk_request_exit", "ptk_synchronize", "ptk_last_error", "ptk_accum_device_ptr", "ptk_rgb8_device_ptr",
     "ptk_bind_accum", "ptk_set_stream", "ptk_gather_accum", "ptk_set_option", "ptk_last_render_ms",
     "ptk_last_kernel_ms", "ptk_collect_stats",
-    "ptk_bvh_info", "ptk_probe_hits", "ptk_probe_primary_dirs",
+    "ptk_bvh_info", "ptk_probe_hits", "ptk_probe_primary_dirs", "ptk_host_alloc", "ptk_host_free",
 ]
 
 
@@ -87,6 +87,8 @@ def load() -> C.CDLL:
     L.ptk_render.argtypes = [vp, u32, u32, u64]
     L.ptk_resolve_rgb8.argtypes = [vp, vp]
     L.ptk_read_accum.argtypes = [vp, vp]
+    L.ptk_host_alloc.restype = vp; L.ptk_host_alloc.argtypes = [C.c_size_t]
+    L.ptk_host_free.restype = None; L.ptk_host_free.argtypes = [vp]
     L.ptk_write_accum.argtypes = [vp, vp, i32]
     L.ptk_samples.argtypes = [vp]
     L.ptk_request_exit.argtypes = [vp]

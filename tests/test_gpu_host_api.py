@@ -154,3 +154,26 @@ def test_exit_from_another_thread(tmp_path):
     assert pt.GetSamples() == 2 and pt.ReadAccumulation().any()
     print(f"render with Exit() after 10 ms took {dt*1e3:.1f} ms, UI polled {len(seen)} times")
     pt.close()
+
+
+def test_page_locked_handoff_buffer(tmp_path):
+    """Progressive display hand-off: RenderFrame() into a page-locked buffer from
+    AllocOutImage() (ptk_host_alloc) delivers the same RGB8 frame as into ordinary memory."""
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer
+    pts, scene, _ = S.build_config("C1", str(tmp_path), width=96, height=64)
+    frames = []
+    for pinned in (False, True):
+        pt = PathTracer(0)
+        pt.LoadSceneFile(pts); pt.SetSeed(5)
+        W, H = pt.GetResolution()
+        out = pt.AllocOutImage() if pinned else np.zeros((H, W, 3), np.uint8)
+        assert out.shape == (H, W, 3) and out.dtype == np.uint8
+        pt.SetOutImage(out)
+        for _ in range(3):
+            pt.RenderFrame()
+        assert pt.LastError() == "" and pt.GetSamples() == 3
+        frames.append(np.array(out))
+        pt.SetOutImage(None)
+        del out, pt
+    assert frames[0].any() and np.array_equal(frames[0], frames[1])

@@ -18,7 +18,7 @@ if os.environ.get('PTK_TILE'):
 best=1e9
 for rep in range(3):
     c.reset(); c.render(0, spp, 1); c.synchronize(); tm, am = c.last_kernel_ms(); best=min(best,tm+am)
-st = c.collect_stats(0, min(spp,16), 1); s = st["samples"]
+st = c.collect_stats(0, int(os.environ.get("PTK_STATS_SPP", min(spp,16))), 1); s = st["samples"]
 print(f"{cfg} spp{spp} opts[{os.environ.get('PTK_OPTS','')}]: {best:.1f} ms -> {W*H*spp/best/1e3:.0f} Msamples/s | util walk %.3f shade %.3f gen %.3f | per 64 samples: walk iters %.1f shade %.2f gen %.2f | nodes %.1f tris %.1f rays %.2f | tri arm util %.3f execs/64 %.1f" % (
     st["walk_lane_iters"]/max(1,st["walk_wave_iters"])/64, st["shade_lanes"]/max(1,st["shade_wave_execs"])/64, st["gen_lanes"]/max(1,st["gen_wave_execs"])/64,
     st["walk_wave_iters"]*64/s, st["shade_wave_execs"]*64/s, st["gen_wave_execs"]*64/s, st["node_visits"]/s, st["tri_tests"]/s, st["rays"]/s, st["tri_lanes"]/max(1,st["tri_wave_execs"])/64, st["tri_wave_execs"]*64/s))
