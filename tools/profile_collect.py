@@ -28,11 +28,12 @@ def dispatches(d, kernel_substr):
 
 
 def full_launches(ds):
-    """the full-size launches (largest grid), i.e. not the 1-spp set-up launch or the stats variant's"""
+    """the full-size launches = the long ones (not the 1-spp set-up launch or the short counters-enabled run); the grid
+    size does not tell them apart: big launches run as a fixed number of persistent waves"""
     if not ds:
         return []
-    g = max(x["grid"] for x in ds)
-    return [x for x in ds if x["grid"] == g]
+    longest = max(x["ms"] for x in ds)
+    return [x for x in ds if x["ms"] >= 0.5 * longest]
 
 
 for c in ("C1", "C2", "C3", "C4", "C5"):
@@ -84,7 +85,8 @@ for c in ("C2", "C4"):
         m["wave_life_issuing_valu"] = m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"]
         m["wave_life_waiting_to_issue"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
         m["avg_waves_per_simd"] = m["SQ_WAVE_CYCLES"] * 4 / (m["ms"] * 1e-3 * 2.4e9) / 1024
-        m["valu_pipe_busy"] = m["wave_life_issuing_valu"] * m["avg_waves_per_simd"]
+        m["valu_pipe_busy"] = min(1.0, m["wave_life_issuing_valu"] * m["avg_waves_per_simd"])
+        m["clock_assumed_GHz"] = 2.4        # avg_waves_per_simd and valu_pipe_busy scale with it (the chip clocks lower under load)
         m["units"] = "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are in quad-cycles summed over waves; ms is the kernel time under the profiler"
         json.dump(m, open(os.path.join(dst, f"pmc_sq_trace_kernel_{c}.json"), "w"), indent=1)
         print(c, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in m.items() if k[0].islower()})
