@@ -140,3 +140,35 @@ def test_flat_and_bvh_walks_agree(ctx, oracle_mod):
     walk = ctx.read_accum()
     ctx.set_option("flat", 1)
     assert np.array_equal(flat, ref) and np.array_equal(walk, ref)
+
+
+@pytest.mark.parametrize("golden,aperture", [("tier_s_glass.npz", 0.0), ("tier_s_opacity.npz", None), ("tier_s_cornell.npz", 0.0)])
+def test_work_distribution_modes_agree(ctx, oracle_mod, golden, aperture):
+    """How work reaches the lanes never changes a bit: persistent waves pulling items from the queues, one item
+    per wave, batched queue pops, several generations of waves, other chunk sizes, tile shares - all equal the
+    oracle's accumulator (BVH and FLAT kernels, with and without the primary-hit cache / live-quadrant list)."""
+    z = load_golden(golden)
+    arrays = scene_from_golden(z); cam = _cam(z, aperture)
+    W, H, D, spp = 150, 70, 5, 24
+    ref, ref8, got, got8 = _both(ctx, oracle_mod, arrays, cam, W, H, D, spp)
+    assert np.array_equal(ref, got) and np.array_equal(ref8, got8)
+    defaults = {"persistent": -1, "generations": 0, "max_batch": 1, "chunk": 0, "tri_threshold": 4}
+    for opts in ({"persistent": 1}, {"persistent": 0}, {"persistent": 1, "max_batch": 7}, {"persistent": 1, "generations": 3, "chunk": 2},
+                 {"persistent": 1, "chunk": 24}, {"persistent": 0, "chunk": 3}, {"persistent": 1, "tri_threshold": 0}, {"persistent": 1, "tri_threshold": 64}):
+        for k, v in {**defaults, **opts}.items():
+            ctx.set_option(k, v)
+        ctx.reset(); ctx.render(0, spp, 5)
+        assert np.array_equal(ctx.read_accum(), got), opts
+        assert np.array_equal(ctx.resolve_rgb8(), got8), opts
+    # tile shares under persistent waves: three ranks' images are disjoint and sum to the whole
+    ctx.set_option("persistent", 1); ctx.set_option("generations", 2); ctx.set_option("chunk", 0); ctx.set_option("tri_threshold", 4)
+    total = np.zeros_like(got)
+    for r in range(3):
+        ctx.set_tile(r, 3); ctx.reset(); ctx.render(0, spp, 5)
+        part = ctx.read_accum()
+        assert not np.any((part != 0) & (total != 0))
+        total += part
+    assert np.array_equal(total, got)
+    ctx.set_tile(0, 1)
+    for k, v in defaults.items():
+        ctx.set_option(k, v)
