@@ -5,8 +5,8 @@
 
 A "step" is one pass of the hot path over one batch: `spp` samples per pixel of the configured frame
 (default BASELINE.json configs[1]: Cornell box, 1280x720, 8 bounces, 256 spp), i.e. 256 RenderFrame()
-calls as one trace_kernel + one accumulate_kernel launch, followed — for N > 1 — by the exchange step (sum-reduce of the
-float accumulator to rank 0 over RCCL).  The scene (replicated), the accumulator and the primary-ray
+calls as one trace_kernel + one accumulate_kernel launch, followed — for N > 1 — by the exchange step (RCCL gather of
+every rank's owned tiles to rank 0).  The scene (replicated), the accumulator and the primary-ray
 table are resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), the frame
 is tile-split across ranks (16x16 tiles, round-robin), total work fixed -> "strong" scaling.
 
@@ -179,7 +179,7 @@ def main():
     ctx.reset()
 
     from pbrpathtracer_amd.distributed import AccumulatorExchange
-    exchange = AccumulatorExchange(accum, dst=0) if (world > 1 or args.force_exchange) else None
+    exchange = AccumulatorExchange(accum, dst=0, width=W, height=H) if (world > 1 or args.force_exchange) else None
 
     def step(first):
         ctx.render(first, spp, args.seed)
@@ -297,7 +297,8 @@ def main():
                        "name": args.config, "width": W, "height": H, "max_depth": D, "spp_per_step": spp,
                        "triangles": ntri, "bvh_nodes": nodes, "bvh_depth": depth,
                        "parallelism": f"tile-split x{world}" if world > 1 else "single GPU",
-                       "exchange": "RCCL sum-reduce of the float accumulator to rank 0, once per step" if world > 1 else "none"},
+                       "exchange": ("RCCL gather of each rank's owned tiles (packed, 1/N of the float accumulator) to rank 0, once per "
+                                    "step, overlapped with the next step's trace kernel") if world > 1 else "none"},
             "roofline": roofline,
             "host": {"scene_gen_s": round(t_gen, 3), "scene_load_bvh_upload_s": round(t_load, 3)},
         }

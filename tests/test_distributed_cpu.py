@@ -66,3 +66,47 @@ def test_tile_masks_partition_the_frame():
     # load balance of the benchmark frame: every rank owns the same number of tiles +- 1
     counts = [D.owned_tile_count(1280, 720, r, 8) for r in range(8)]
     assert max(counts) - min(counts) <= 1
+
+
+def _exchange_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from pbrpathtracer_amd import distributed as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H = 70, 50                                   # ragged: 5 x 4 tiles, the last column / row partial
+    rng = np.random.default_rng(123)
+    full = rng.random((H, W, 3), dtype=np.float32) + 1.0            # what a single rank would hold (rows bottom-up)
+    mask = D.tile_owner_mask(W, H, rank, world)[::-1]
+    mine = np.where(mask[..., None], full, 0.0).astype(np.float32)
+    ok = []
+    for mode in ("gather", "reduce"):
+        local = torch.from_numpy(mine.reshape(-1).copy())
+        ex = D.AccumulatorExchange(local, dst=0, width=W, height=H, mode=mode)
+        assert ex.mode == mode
+        ex.start()
+        res = ex.wait()
+        # a second batch: the local accumulator has grown, the exchange object is re-used
+        local += torch.from_numpy(mine.reshape(-1))
+        ex.start()
+        res2 = ex.wait().clone()
+        if rank == 0:
+            ok += [np.array_equal(res2.numpy().reshape(H, W, 3), 2 * full)]
+    lens = [len(D.owned_float_index(W, H, r, world)) for r in range(world)]
+    if rank == 0:
+        ok += [sum(lens) == W * H * 3, len(set(lens)) > 1 or world == 1]          # complete, and uneven in this frame
+        np.save(os.path.join(out_dir, "ok.npy"), np.array(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_packed_gather_exchange(tmp_path, world):
+    """AccumulatorExchange: every rank sends only its owned values (uneven counts, padded to the longest) and rank 0
+    scatters them into place; equals the sum-reduce form and the single-rank image, also on re-use."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_exchange_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert np.load(str(tmp_path / "ok.npy")).all()
