@@ -196,6 +196,15 @@ def main():
         torch.cuda.synchronize()
 
     first = 0
+    if exchange is not None:
+        # one untimed exchange up front: if the packed gather is not available in this RCCL / torch build every rank
+        # falls back to the sum-reduce form together (same result, 8x the payload)
+        try:
+            exchange.start(); exchange.wait(); torch.cuda.synchronize()
+        except Exception as e:                              # pragma: no cover - depends on the installed collectives
+            if rank == 0:
+                print(f"bench.py: packed exchange unavailable ({type(e).__name__}: {e}); using reduce", file=sys.stderr)
+            exchange = AccumulatorExchange(accum, dst=0, mode="reduce")
     for _ in range(args.warmup):
         step(first); first += spp
     fence()
@@ -297,8 +306,9 @@ def main():
                        "name": args.config, "width": W, "height": H, "max_depth": D, "spp_per_step": spp,
                        "triangles": ntri, "bvh_nodes": nodes, "bvh_depth": depth,
                        "parallelism": f"tile-split x{world}" if world > 1 else "single GPU",
-                       "exchange": ("RCCL gather of each rank's owned tiles (packed, 1/N of the float accumulator) to rank 0, once per "
-                                    "step, overlapped with the next step's trace kernel") if world > 1 else "none"},
+                       "exchange": (("RCCL gather of each rank's owned tiles (packed, 1/N of the float accumulator)" if exchange.mode == "gather"
+                                     else "RCCL sum-reduce of the float accumulator") + " to rank 0, once per step, overlapped with "
+                                    "the next step's trace kernel") if world > 1 else "none"},
             "roofline": roofline,
             "host": {"scene_gen_s": round(t_gen, 3), "scene_load_bvh_upload_s": round(t_load, 3)},
         }
