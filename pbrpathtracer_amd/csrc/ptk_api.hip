@@ -821,7 +821,8 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     }
     if (!std::strcmp(name, "pass_bytes"))
     {
-        if (!(value >= 1 << 20)) return fail(c, PTK_ERR_BAD_ARG, "pass_bytes must be >= 1 MiB");
+        // upper bound: the kernel indexes the sample buffer (16-byte entries) with 32 bits
+        if (!(value >= 1 << 20 && value <= 32.0 * 1073741824.0)) return fail(c, PTK_ERR_BAD_ARG, "pass_bytes must be in [1 MiB, 32 GiB]");
         c->opt_pass_bytes = (size_t)value;
         return PTK_OK;
     }
