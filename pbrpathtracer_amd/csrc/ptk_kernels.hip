@@ -669,11 +669,14 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
                 }
                 const int nt = __popcll(__ballot(st == ST_TRAV));
                 const int ns = __popcll(__ballot(st == ST_SHADE));
-                const int ng = __popcll(__ballot(st == ST_GEN));
+                // a lane whose path ended in the walk (its ray left the scene) waits in NEED for a new unit: it runs
+                // up the same debt as a lane waiting for the camera-ray block, and is dealt its unit first
+                const unsigned long long m_nd = __ballot(st == ST_NEED);
+                const int ng = __popcll(__ballot(st == ST_GEN)) + __popcll(m_nd);
                 const int nl = nt + ns + ng;
                 debt_shade += ns; debt_gen += ng;
                 if (ns > 0 && debt_shade * 8 >= P.shade_thr * (nl - ns)) { run_shade = true; break; }
-                if (ng > 0 && debt_gen * 8 >= P.gen_thr * (nl - ng)) { run_gen = true; break; }
+                if (ng > 0 && debt_gen * 8 >= P.gen_thr * (nl - ng)) { run_gen = m_nd == 0ull; break; }   // NEED lanes: re-vote via the top of the loop
                 if (nt == 0) break;
             } while (true);
             if (!run_shade && !run_gen) continue;        // the walk ran dry: re-vote

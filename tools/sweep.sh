@@ -1,2 +1,1 @@
-for e in "PTK_LEAF_MAX=4" "PTK_LEAF_MAX=2" "PTK_LEAF_MAX=3" "PTK_LEAF_MAX=6" "PTK_TRAV_COST=0.5" "PTK_TRAV_COST=2" "PTK_TRAV_COST=4"; do echo "== $e"; env $e PTK_STATS_SPP=64 timeout -k 10 100 python tools/stats_probe.py C4 256 | cut -c1-210; done
-for e in "PTK_LEAF_MAX=4" "PTK_LEAF_MAX=2" "PTK_TRAV_COST=2"; do echo "== $e"; env $e PTK_STATS_SPP=64 timeout -k 10 100 python tools/stats_probe.py C5 256 | cut -c1-210; done
+for c in C2 C3 C4 C5; do PTK_STATS_SPP=64 timeout -k 10 100 python tools/stats_probe.py $c 256 | cut -c1-200; done
