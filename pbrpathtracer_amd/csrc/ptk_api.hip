@@ -70,6 +70,11 @@ struct ptk_ctx {
     float4* d_samples = nullptr;
     size_t samples_bytes = 0;
     int opt_chunk = 0;                           // samples per work item; 0 = automatic (8, or 4 for small shares)
+    int opt_wavefront = 0;                       // BVH scenes: 1 = walk stage / shade stage kernels over path queues instead of one kernel
+    size_t opt_wavefront_paths = (size_t)48 << 20;  // paths (128-byte records) parked at once = samples per wavefront pass
+    float4* d_paths = nullptr; unsigned* d_cont_q = nullptr; unsigned* d_shade_q = nullptr; unsigned* d_wq = nullptr;
+    size_t wf_capacity = 0;                      // entries the three buffers above hold
+    int num_cus = 256;
     int opt_generations = 0;                     // 0 automatic: 1 on a single GPU, 2 when the frame is split over ranks
     int opt_persistent = -1;                     // -1 automatic (by launch size), 0 one item per wave, 1 persistent waves
     int opt_max_batch = 1;                       // slots a persistent wave pops from its queue at once; > 1 measured slower everywhere
@@ -261,6 +266,9 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
     if (chunk_opt <= 0)
         chunk_opt = (double)spp * (double)tiles * 4.0 / 8.0 >= 49152.0 ? 8 : 4;
     uint32_t max_pass = (uint32_t)std::max<size_t>(1, c->opt_pass_bytes / per_sample);
+    const bool wavefront = c->opt_wavefront != 0 && p.flat_count == 0 && c->num_tris > 0;
+    if (wavefront)      // every sample of a pass is a parked path at some point: bound the pass by the path store
+        max_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(max_pass, c->opt_wavefront_paths / ((size_t)tiles * 4 * 64)));
     if (max_pass > (uint32_t)chunk_opt) max_pass -= max_pass % (uint32_t)chunk_opt;
     uint32_t done = 0;
     while (done < spp)
@@ -286,7 +294,38 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         const int pi = c->last_passes < ptk_ctx::kMaxTimedPasses ? c->last_passes : -1;
         if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][0], c->stream));
         p.queues = c->d_queues;
-        launch_trace(p, tiles * 4, c->resident_waves, c->stream, stats);
+        if (wavefront)
+        {
+            const size_t entries = (size_t)tiles * 4 * 64 * (size_t)chunk * num_chunks;
+            if (entries > c->wf_capacity)
+            {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                dfree(c->d_paths); dfree(c->d_cont_q); dfree(c->d_shade_q); c->wf_capacity = 0;
+                HIPCHK(c, hipMalloc(&c->d_paths, entries * 8 * sizeof(float4)));
+                // (+ the blocks of 256 entries that waves reserve and may leave partly unused: two per resident wave at most)
+                const size_t qcap = entries + (size_t)c->num_cus * 32 * 2 * 256;
+                HIPCHK(c, hipMalloc(&c->d_cont_q, qcap * sizeof(unsigned)));
+                HIPCHK(c, hipMalloc(&c->d_shade_q, qcap * sizeof(unsigned)));
+                c->wf_capacity = entries;
+            }
+            if (!c->d_wq) HIPCHK(c, hipMalloc(&c->d_wq, 128 * sizeof(unsigned)));
+            p.paths = c->d_paths; p.cont_q = c->d_cont_q; p.shade_q = c->d_shade_q; p.wq = c->d_wq;
+            // enough rounds for every path that does not survive Russian roulette beyond the depth; then look
+            int rounds = c->max_depth + 2;
+            bool first_launch = true;
+            for (int guard = 0; guard < 64; guard++)
+            {
+                launch_wavefront(p, tiles * 4, c->num_cus, rounds, first_launch, c->stream, stats);
+                HIPCHK(c, hipGetLastError());
+                first_launch = false;
+                unsigned waiting = 0;                    // paths the last walk stage queued for shading
+                HIPCHK(c, hipMemcpyAsync(&waiting, c->d_wq + 96, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (waiting == 0) break;
+                rounds = 4;
+            }
+        }
+        else launch_trace(p, tiles * 4, c->resident_waves, c->stream, stats);
         HIPCHK(c, hipGetLastError());
         if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][1], c->stream));
         launch_accumulate(p, tiles, c->stream);
@@ -320,6 +359,7 @@ int ptk_create(ptk_ctx** out, int device_ordinal)
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0)
             c->resident_waves = cus * 16;        // 4 SIMDs x 4 waves of trace_kernel (112-114 VGPRs) per CU
+        if (cus > 0) c->num_cus = cus;
     }
     if (hipMalloc(&c->d_exit, sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_exit, 0, sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&c->d_stats, 16 * sizeof(unsigned long long)) != hipSuccess ||
@@ -343,6 +383,7 @@ void ptk_destroy(ptk_ctx* c)
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_mats); dfree(c->d_lights);
     dfree(c->d_texinfo); dfree(c->d_texels); dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_accum); dfree(c->d_rgb8);
     dfree(c->d_exit); dfree(c->d_stats); dfree(c->d_queues); dfree(c->d_samples);
+    dfree(c->d_paths); dfree(c->d_cont_q); dfree(c->d_shade_q); dfree(c->d_wq);
     dfree(c->d_live_mask); dfree(c->d_live_list);
     for (int i = 0; i < ptk_ctx::kMaxTimedPasses; i++)
         for (int k = 0; k < 3; k++)
@@ -777,6 +818,17 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     {
         if (!(value >= 0 && value <= 4096)) return fail(c, PTK_ERR_BAD_ARG, "threshold (lambda in eighths) must be in [0, 4096]");
         (name[0] == 's' ? c->opt_shade_thr : c->opt_gen_thr) = (int)value;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "wavefront"))
+    {
+        c->opt_wavefront = value != 0.0 ? 1 : 0;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "wavefront_paths"))
+    {
+        if (!(value >= 65536 && value <= 1073741824.0)) return fail(c, PTK_ERR_BAD_ARG, "wavefront_paths must be in [64 Ki, 1 Gi]");
+        c->opt_wavefront_paths = (size_t)value;
         return PTK_OK;
     }
     if (!std::strcmp(name, "generations"))

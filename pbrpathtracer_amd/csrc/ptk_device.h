@@ -53,6 +53,12 @@ struct RenderParams {
     int chunk, num_chunks;      // samples per work item, work items per 8x8 tile
     int num_items;              // owned tiles * 4 * num_chunks
     int max_batch;              // most slots a wave pops from a queue at once
+    // wavefront formulation (trace_kernel MODE 1 / 2): parked paths, their queues and the queue counters
+    float4* paths;              // 8 float4 per path, indexed by the path's sample-buffer slot
+    unsigned* cont_q;           // ids of paths that wait for their next walk
+    unsigned* shade_q;          // ids of paths that wait for shading
+    unsigned* wq;               // WQ_* counters
+    int units_enabled;          // walk stage: 1 = also starts new paths from the work items (first launch of a pass)
     int generations;            // persistent launches: waves retire after 1/generations of their share (1 = never)
     int persistent;             // 1: resident waves pull items from the queues; 0: one item per wave, named by blockIdx
     const unsigned long long* live_mask;   // per owned quadrant: its pixels that need tracing
@@ -109,6 +115,7 @@ struct ProbeParams {
 };
 
 void launch_trace(const RenderParams& p, int num_subtiles, int resident_waves, hipStream_t stream, bool stats);
+void launch_wavefront(const RenderParams& p, int num_subtiles, int cus, int rounds, bool first, hipStream_t stream, bool stats);
 void launch_live_list(const RenderParams& p, int num_subtiles, unsigned long long* mask, unsigned* list, unsigned* count, hipStream_t stream);
 void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t stream);
 void launch_primary(const PrimaryParams& p, hipStream_t stream);

@@ -367,11 +367,23 @@ enum : int { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_DONE = 3, ST_NEED = 4 };
 // lane tests every triangle, the records are fetched with SCALAR loads (one s_load per triangle per
 // wave, operands broadcast from SGPRs, no vector memory traffic and no LDS stack), and the whole walk
 // is one block of the state machine, so lanes re-synchronise by themselves.
-template <bool STATS, bool FLAT>
+// MODE 0: the whole path loop in one kernel (every state of the lane state machine).
+// MODE 1 / 2: the two stages of the WAVEFRONT formulation for deep scenes - 1 = camera rays + BVH walks, 2 = surface
+// interactions - run alternately; a lane that reaches the other stage's state parks its path in HBM (128-byte
+// record, P.paths) and queues its id for the other kernel, then takes the next path from its own stage's queue, so
+// every lane of every wave does the same kind of work (the single kernel shades with 1/3 of the lanes on C4).
+enum : int { MODE_MEGA = 0, MODE_WALK = 1, MODE_SHADE = 2 };
+enum : int { WQ_CONT_HEAD = 0, WQ_CONT_TAIL = 32, WQ_SHADE_HEAD = 64, WQ_SHADE_TAIL = 96, WQ_WORDS = 128 };   // one counter per 128-B line
+enum : uint32_t { WQ_BLOCK = 256u, WQ_NONE = 0xffffffffu };    // queue entries reserved / popped per atomic; an unused entry
+
+template <bool STATS, bool FLAT, int MODE>
 __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel(const RenderParams P)
 {
-    __shared__ int lds_stack[FLAT ? 1 : PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
+    static_assert(MODE == MODE_MEGA || !FLAT, "the wavefront stages exist for the BVH walk only");
+    __shared__ int lds_stack[(FLAT || MODE == MODE_SHADE) ? 1 : PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
     if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (MODE == MODE_WALK && !P.units_enabled && P.wq[WQ_CONT_TAIL] == 0u) return;          // nothing queued for this round
+    if (MODE == MODE_SHADE && P.wq[WQ_SHADE_TAIL] == 0u) return;
 
     const int tid = threadIdx.x;
     int* stack = lds_stack + tid;
@@ -558,9 +570,89 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     } while (0)
 
     int debt_shade = 0, debt_gen = 0;      // wave-uniform: lane-iterations wasted by parked lanes
+    bool queue_dry = false;                // wavefront stages: this stage's queue has been popped past its end
+    uint32_t pop_lo = 0, pop_hi = 0;       // ... entries of it this wave has popped and not yet handed to a lane
+    uint32_t res_base = 0, res_left = 0;   // ... space this wave has reserved in the other stage's queue
     for (;;)
     {
+        if (MODE != MODE_MEGA)
+        {
+            // ---- wavefront: park the paths that reached the other stage, take queued ones of this stage ----
+            const int other = MODE == MODE_WALK ? ST_SHADE : ST_TRAV;
+            const unsigned long long m_out = __ballot(st == other);
+            if (m_out)
+            {
+                // queue space is reserved WQ_BLOCK entries at a time (one atomic per block, not per push: a single
+                // counter takes ~90 atomics/us); what a wave leaves unused of its block holds WQ_NONE
+                unsigned* outq = MODE == MODE_WALK ? P.shade_q : P.cont_q;
+                const uint32_t n_out = (uint32_t)__popcll(m_out);
+                if (res_left < n_out)
+                {
+                    for (uint32_t i = (uint32_t)lane; i < res_left; i += 64u) outq[res_base + i] = WQ_NONE;
+                    uint32_t nb = 0;
+                    if (lane == 0) nb = atomicAdd(&P.wq[MODE == MODE_WALK ? WQ_SHADE_TAIL : WQ_CONT_TAIL], (uint32_t)WQ_BLOCK);
+                    res_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+                    res_left = WQ_BLOCK;
+                }
+                const uint32_t base = res_base;
+                res_base += n_out; res_left -= n_out;
+                if (st == other)
+                {
+                    float4* rec = P.paths + (size_t)out_idx * 8;
+                    rec[0] = make_float4(W.ro.x, W.ro.y, W.ro.z, W.rd.x);
+                    rec[1] = make_float4(W.rd.y, W.rd.z, W.best.t, W.best.u);
+                    rec[2] = make_float4(W.best.v, __int_as_float(W.best.tri), L.x, L.y);
+                    rec[3] = make_float4(L.z, T.x, T.y, T.z);
+                    rec[4] = make_float4(Tdi.x, Tdi.y, Tdi.z, nextDir.x);
+                    rec[5] = make_float4(nextDir.y, nextDir.z, W.occl_limit, __int_as_float(W.occl_tri));
+                    rec[6] = make_float4(__uint_as_float(rng.state), __uint_as_float(rng.inc), __uint_as_float(rng.key), __uint_as_float(out_idx));
+                    rec[7] = make_float4(__int_as_float(depth), __int_as_float(iter), __int_as_float(inside ? 1 : 0), __uint_as_float(ray));
+                    outq[base + (uint32_t)__popcll(m_out & ((1ull << lane) - 1ull))] = out_idx;
+                    st = ST_NEED;
+                }
+            }
+            unsigned long long m_need = __ballot(st == ST_NEED);
+            while (m_need && !(queue_dry && pop_lo >= pop_hi))
+            {
+                if (pop_lo >= pop_hi)
+                {
+                    uint32_t nb = 0;
+                    if (lane == 0) nb = atomicAdd(&P.wq[MODE == MODE_WALK ? WQ_CONT_HEAD : WQ_SHADE_HEAD], (uint32_t)WQ_BLOCK);
+                    nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+                    const uint32_t tail = P.wq[MODE == MODE_WALK ? WQ_CONT_TAIL : WQ_SHADE_TAIL];   // fixed while this kernel runs
+                    pop_lo = min(nb, tail); pop_hi = min(nb + (uint32_t)WQ_BLOCK, tail);
+                    queue_dry = nb + (uint32_t)WQ_BLOCK >= tail;
+                    if (pop_lo >= pop_hi) break;
+                }
+                const uint32_t mine = pop_lo + (uint32_t)__popcll(m_need & ((1ull << lane) - 1ull));
+                const uint32_t take = min((uint32_t)__popcll(m_need), pop_hi - pop_lo);
+                uint32_t id = WQ_NONE;
+                if (st == ST_NEED && mine < pop_hi) id = (MODE == MODE_WALK ? P.cont_q : P.shade_q)[mine];
+                pop_lo += take;
+                if (id != WQ_NONE)
+                {
+                    out_idx = id;
+                    const float4* rec = P.paths + (size_t)out_idx * 8;
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6], r7 = rec[7];
+                    W.begin(V(r0.x, r0.y, r0.z), V(r0.w, r1.x, r1.y), P.num_nodes);     // (a fresh walk for MODE_WALK)
+                    if (MODE == MODE_SHADE) { W.best.t = r1.z; W.best.u = r1.w; W.best.v = r2.x; W.best.tri = __float_as_int(r2.y); }
+                    L = V(r2.z, r2.w, r3.x); T = V(r3.y, r3.z, r3.w);
+                    Tdi = V(r4.x, r4.y, r4.z); nextDir = V(r4.w, r5.x, r5.y);
+                    W.occl_limit = r5.z; W.occl_tri = __float_as_int(r5.w);
+                    rng.state = __float_as_uint(r6.x); rng.inc = __float_as_uint(r6.y); rng.key = __float_as_uint(r6.z);
+                    depth = __float_as_int(r7.x); iter = __float_as_int(r7.y); inside = __float_as_int(r7.z) != 0; ray = __float_as_uint(r7.w);
+                    st = MODE == MODE_WALK ? ST_TRAV : ST_SHADE;
+                }
+                m_need = __ballot(st == ST_NEED);
+            }
+            if (MODE == MODE_SHADE || !P.units_enabled)
+            {
+                // no camera rays in this launch: lanes the queue could not feed are finished
+                if (st == ST_NEED && queue_dry && pop_lo >= pop_hi) st = ST_DONE;
+            }
+        }
         // deal the next work units to the lanes that need one (wave-uniform code)
+        if (MODE == MODE_MEGA || (MODE == MODE_WALK && P.units_enabled))
         {
             unsigned long long m_need = __ballot(st == ST_NEED);
             while (m_need)
@@ -644,7 +736,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
             run_shade = n_shade > 0 && (sc_shade >= sc_gen || n_gen == 0);
             run_gen = !run_shade;
         }
-        else if (n_trav > 0)
+        else if (MODE != MODE_SHADE && n_trav > 0)
         {
             // ---- BVH walk ----
             do
@@ -675,14 +767,16 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
                 const int ng = __popcll(__ballot(st == ST_GEN)) + __popcll(m_nd);
                 const int nl = nt + ns + ng;
                 debt_shade += ns; debt_gen += ng;
-                if (ns > 0 && debt_shade * 8 >= P.shade_thr * (nl - ns)) { run_shade = true; break; }
+                if (ns > 0 && debt_shade * 8 >= (MODE == MODE_WALK ? P.gen_thr : P.shade_thr) * (nl - ns)) { run_shade = true; break; }
                 if (ng > 0 && debt_gen * 8 >= P.gen_thr * (nl - ng)) { run_gen = m_nd == 0ull; break; }   // NEED lanes: re-vote via the top of the loop
                 if (nt == 0) break;
             } while (true);
             if (!run_shade && !run_gen) continue;        // the walk ran dry: re-vote
         }
         if (run_shade) debt_shade = 0; else debt_gen = 0;
-        if (run_shade)
+        if (MODE == MODE_WALK && run_shade) continue;       // hits are parked for the shade stage at the top of the loop
+        if (MODE == MODE_SHADE && !run_shade) continue;
+        if (MODE != MODE_WALK && run_shade)
         {
             if (STATS) { const uint32_t nsx = (uint32_t)__popcll(__ballot(st == ST_SHADE)); if (lane == 0) { cnt.shade_execs++; cnt.shade_lanes += nsx; } }
             if (st == ST_SHADE)
@@ -889,7 +983,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
                 if (ended) PTK_FINISH_PATH();
             }
         }
-        else
+        else if (MODE != MODE_SHADE)
         {
             if (STATS) { const uint32_t ngx = (uint32_t)__popcll(__ballot(st == ST_GEN)); if (lane == 0) { cnt.gen_execs++; cnt.gen_lanes += ngx; } }
             if (st == ST_GEN)
@@ -935,6 +1029,8 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel
     }
 #undef PTK_WALK_DONE
 #undef PTK_FINISH_PATH
+    if (MODE != MODE_MEGA)      // what is left of the last reserved queue block stays empty
+        for (uint32_t i = (uint32_t)lane; i < res_left; i += 64u) (MODE == MODE_WALK ? P.shade_q : P.cont_q)[res_base + i] = WQ_NONE;
 
     if (STATS)
     {
@@ -1148,11 +1244,68 @@ void launch_trace(const RenderParams& p0, int num_subtiles, int resident_waves, 
     geo.w[QG_QUOTA] = generations > 1 ? blocks : 0;
     hipLaunchKernelGGL(queue_init_kernel, dim3(1), dim3(64), 0, stream, p.queues, geo, p.live_count);
     const bool flat = p.flat_count > 0;
-    if (stats && flat) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    else if (stats) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    else if (flat) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    if (stats && flat) hipLaunchKernelGGL((trace_kernel<true, true, MODE_MEGA>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else if (stats) hipLaunchKernelGGL((trace_kernel<true, false, MODE_MEGA>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else if (flat) hipLaunchKernelGGL((trace_kernel<false, true, MODE_MEGA>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else hipLaunchKernelGGL((trace_kernel<false, false, MODE_MEGA>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
 }
+
+// ---- wavefront formulation (BVH scenes): walk stage and shade stage alternate over path queues in HBM ----
+__global__ void wavefront_flip_kernel(unsigned* wq, int next_stage)
+{
+    // before the walk stage (1): it consumes the continuation queue from its start and refills the shade queue;
+    // before the shade stage (2): the other way round; 0: a new pass, everything empty
+    if (threadIdx.x != 0) return;
+    if (next_stage == 0) { wq[WQ_CONT_HEAD] = wq[WQ_CONT_TAIL] = wq[WQ_SHADE_HEAD] = wq[WQ_SHADE_TAIL] = 0u; }
+    else if (next_stage == MODE_WALK) { wq[WQ_CONT_HEAD] = 0u; wq[WQ_SHADE_HEAD] = wq[WQ_SHADE_TAIL] = 0u; }
+    else { wq[WQ_SHADE_HEAD] = 0u; wq[WQ_CONT_HEAD] = wq[WQ_CONT_TAIL] = 0u; }
+}
+
+int wavefront_resident_waves(bool stats, int stage, int cus)
+{
+    int per_cu = 0;
+    hipError_t e;
+    if (stage == MODE_WALK)
+        e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<true, false, MODE_WALK>, PTK_TRACE_BLOCK, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, false, MODE_WALK>, PTK_TRACE_BLOCK, 0);
+    else
+        e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<true, false, MODE_SHADE>, PTK_TRACE_BLOCK, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, false, MODE_SHADE>, PTK_TRACE_BLOCK, 0);
+    if (e != hipSuccess || per_cu <= 0) per_cu = 16;
+    return per_cu * cus;
+}
+
+// One pass of the wavefront formulation: camera rays + first walks, then `rounds` x (shade stage, walk stage).  A stage
+// whose queue is empty returns at once, so a generous `rounds` costs launches, not work; the caller checks the queues
+// afterwards (paths that survive Russian roulette for longer are possible, if rare) and runs more rounds if needed.
+void launch_wavefront(const RenderParams& p0, int num_subtiles, int cus, int rounds, bool first, hipStream_t stream, bool stats)
+{
+    if (num_subtiles <= 0) return;
+    RenderParams p = p0;
+    const int walk_blocks = wavefront_resident_waves(stats, MODE_WALK, cus), shade_blocks = wavefront_resident_waves(stats, MODE_SHADE, cus);
+    if (first)
+    {
+        QueueGeometry geo = {};
+        geo.w[QG_NUM_CHUNKS] = p.num_chunks; geo.w[QG_WORLD] = p.world; geo.w[QG_RANK] = p.rank;
+        geo.w[QG_TILES_X] = p.tiles_x; geo.w[QG_CHUNK] = p.chunk; geo.w[QG_SPP] = (int)p.spp;
+        hipLaunchKernelGGL(queue_init_kernel, dim3(1), dim3(64), 0, stream, p.queues, geo, p.live_count);
+        hipLaunchKernelGGL(wavefront_flip_kernel, dim3(1), dim3(64), 0, stream, p.wq, 0);
+        p.persistent = 1; p.units_enabled = 1;
+        if (stats) hipLaunchKernelGGL((trace_kernel<true, false, MODE_WALK>), dim3(walk_blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+        else hipLaunchKernelGGL((trace_kernel<false, false, MODE_WALK>), dim3(walk_blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    }
+    p.persistent = 1; p.units_enabled = 0;
+    for (int r = 0; r < rounds; r++)
+    {
+        hipLaunchKernelGGL(wavefront_flip_kernel, dim3(1), dim3(64), 0, stream, p.wq, (int)MODE_SHADE);
+        if (stats) hipLaunchKernelGGL((trace_kernel<true, false, MODE_SHADE>), dim3(shade_blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+        else hipLaunchKernelGGL((trace_kernel<false, false, MODE_SHADE>), dim3(shade_blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+        hipLaunchKernelGGL(wavefront_flip_kernel, dim3(1), dim3(64), 0, stream, p.wq, (int)MODE_WALK);
+        if (stats) hipLaunchKernelGGL((trace_kernel<true, false, MODE_WALK>), dim3(walk_blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+        else hipLaunchKernelGGL((trace_kernel<false, false, MODE_WALK>), dim3(walk_blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    }
+}
+
 void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t stream)
 {
     if (owned_tiles <= 0) return;
