@@ -66,14 +66,15 @@ class AccumulatorExchange:
     them into place.  Pure copies, so the image is the single-GPU one bit for bit, like the sum-reduce of the
     zero-padded buffers that is used when no geometry is given (mode "reduce")."""
 
-    def __init__(self, local, dst: int = 0, width: int = 0, height: int = 0, mode: str = "gather"):
+    def __init__(self, local, dst: int = 0, width: int = 0, height: int = 0, mode: str = "gather", force: bool = False):
         import torch
         import torch.distributed as dist
         self.local = local
         self.dst = dst
         self.result = torch.zeros_like(local)
         self.cuda = local.is_cuda
-        self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # `force`: run the collective even in a one-rank group (rehearsal of the N > 1 code path on one GPU)
+        self.multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
         self.packed = bool(self.multi and mode == "gather" and width > 0 and height > 0)
         self.mode = "gather" if self.packed else "reduce"
         if self.packed:

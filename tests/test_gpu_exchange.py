@@ -92,10 +92,14 @@ def test_torch_distributed_path_world_1():
         c3.close()
         c2 = _ctx(); c2.reset(); c2.render(0, 10, 11)
         assert np.array_equal(accum.cpu().numpy().reshape(48, 80, 3), c2.read_accum())
-        c.close(); c2.close()
-        return
-        c2 = _ctx(); c2.reset(); c2.render(0, 8, 11)
-        assert np.array_equal(accum.cpu().numpy().reshape(48, 80, 3), c2.read_accum())
+        # the packed form bench.py uses for N > 1 (index_select -> RCCL gather -> index_copy), forced in this one-rank
+        # group: the root's result is the accumulator, through the same calls
+        for mode in ("gather", "reduce"):
+            exp = AccumulatorExchange(accum, dst=0, width=80, height=48, mode=mode, force=True)
+            assert exp.mode == mode
+            exp.start()
+            got = exp.wait(); torch.cuda.synchronize()
+            assert np.array_equal(got.cpu().numpy().reshape(48, 80, 3), c2.read_accum()), mode
         c.close(); c2.close()
     finally:
         dist.destroy_process_group()
