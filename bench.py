@@ -223,11 +223,19 @@ def main():
 
     # kernel time per launch, measured live with HIP events recorded on the kernels' own stream
     # around each launch (trace_kernel and accumulate_kernel separately), over a few more steps
+    # (launch by launch, un-overlapped: in the timed loop above the trace kernel of a batch starts while the previous
+    # one's last few waves - its longest paths - are still finishing, which is what `value` measures; a per-launch
+    # duration only means something in isolation)
     ev_ms, acc_ms = [], []
+    ctx.set_option("overlap", 0)
     for _ in range(min(args.steps, 5)):
         ctx.render(first, spp, args.seed); first += spp
         t_ms, a_ms = ctx.last_kernel_ms()
         ev_ms.append(t_ms); acc_ms.append(a_ms)
+    ctx.set_option("overlap", 1)
+    for kv in args.opts.split(","):
+        if kv.startswith("overlap="):
+            ctx.set_option("overlap", float(kv.split("=")[1]))
     fence()
 
     total_samples = float(W) * H * spp * args.steps

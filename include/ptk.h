@@ -154,7 +154,8 @@ int ptk_gather_accum(ptk_ctx* ctx, void* rccl_comm, int root);
 /* tuning (none changes any result): "chunk" = samples per work item (default 0 = automatic: 8, or 4 when
  * the rank's share of the frame is small); "max_batch" = queue slots a persistent wave pops at once (default 1); "persistent" = -1/0/1: waves pull
  * work items from queues until none is left (1), or one item per wave (0); default -1 = by launch size; "generations" = persistent waves retire after 1/g of their share so that other
- * streams' kernels (the exchange step) get wave slots mid-launch (default 0 = 1 on one GPU, 2 when tile-split: measured cost 0-2 %); "wavefront" = 0/1 (default 0): BVH scenes
+ * streams' kernels (the exchange step) get wave slots mid-launch (default 0 = 1 on one GPU, 2 when tile-split: measured cost 0-2 %); "overlap" = 0/1 (default 1): consecutive batches trace on two alternating internal streams so that a batch's
+ * tail (its few longest paths) overlaps the next batch; results and stream ordering are unchanged; "wavefront" = 0/1 (default 0): BVH scenes
  * run as alternating walk-stage / shade-stage kernels over path queues in HBM (experimental: bit-identical, slower),
  * "wavefront_paths" = paths parked at once (default 48 Mi);
  * "flat" = 0/1, scenes of <= 16 triangles skip the BVH walk and test

@@ -67,8 +67,22 @@ struct ptk_ctx {
     int resident_waves = 4096;                   // one-wave workgroups the device holds at once (CUs x 16)
 
     // sample buffer between trace_kernel and accumulate_kernel (grown on demand, never shrunk)
-    float4* d_samples = nullptr;
+    // Two sample buffers / queue blocks / trace streams: the trace kernel of pass k+1 runs on the other stream and
+    // overlaps the tail of pass k's (a launch ends with the few waves that hold its longest paths - Russian roulette
+    // lets one path in tens of millions live for 60+ bounces, ~0.4 ms with the rest of the chip idle) and pass k's
+    // accumulate kernel.  The accumulate kernels stay on the context's stream, in order, each behind its trace kernel,
+    // so everything the caller orders after ptk_render on that stream still sees the finished batch.
+    float4* d_samples = nullptr;                 // (wavefront / non-overlapped path)
     size_t samples_bytes = 0;
+    float4* d_samples2[2] = { nullptr, nullptr };
+    size_t samples_bytes2[2] = { 0, 0 };
+    unsigned* d_queues2[2] = { nullptr, nullptr };
+    hipStream_t trace_stream[2] = { nullptr, nullptr };
+    hipEvent_t ev_trace_done[2] = { nullptr, nullptr }, ev_acc_done[2] = { nullptr, nullptr }, ev_inputs = nullptr;
+    bool acc_pending[2] = { false, false }, inputs_recorded = false;
+    bool inputs_dirty = true;                    // scene / camera tables were (re)written on the context's stream since ev_inputs
+    unsigned pass_counter = 0;
+    int opt_overlap = 1;
     int opt_chunk = 0;                           // samples per work item; 0 = automatic (8, or 4 for small shares)
     int opt_wavefront = 0;                       // BVH scenes: 1 = walk stage / shade stage kernels over path queues instead of one kernel
     size_t opt_wavefront_paths = (size_t)48 << 20;  // paths (128-byte records) parked at once = samples per wavefront pass
@@ -166,6 +180,7 @@ int ensure_primary(ptk_ctx* c)
     HIPCHK(c, hipGetLastError());
     c->primary_dirty = false;
     c->primary_hit_dirty = true;
+    c->inputs_dirty = true;
     return PTK_OK;
 }
 
@@ -228,6 +243,7 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
             HIPCHK(c, hipGetLastError());
             c->primary_hit_dirty = false;
             c->hit_generation++;
+            c->inputs_dirty = true;
         }
         p.primary_hit = c->d_primary_hit;
     }
@@ -254,6 +270,7 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
             launch_live_list(p, subtiles, c->d_live_mask, c->d_live_list, c->d_live_list + c->live_capacity, c->stream);
             HIPCHK(c, hipGetLastError());
             c->live_key = key;
+            c->inputs_dirty = true;
         }
         p.live_mask = c->d_live_mask; p.live_list = c->d_live_list; p.live_count = c->d_live_list + c->live_capacity;
     }
@@ -277,14 +294,39 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         const int chunk = (int)std::min<uint32_t>(n, (uint32_t)chunk_opt);
         const int num_chunks = (int)((n + chunk - 1) / chunk);
         const size_t need = per_sample * (size_t)chunk * num_chunks;
-        if (need > c->samples_bytes)
+        const bool overlap = !wavefront && c->opt_overlap != 0 && c->trace_stream[0] != nullptr;
+        const int b = (int)(c->pass_counter & 1u);
+        hipStream_t tstream = overlap ? c->trace_stream[b] : c->stream;
+        if (overlap)
         {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            dfree(c->d_samples); c->samples_bytes = 0;
-            HIPCHK(c, hipMalloc(&c->d_samples, need));
-            c->samples_bytes = need;
+            if (need > c->samples_bytes2[b])
+            {
+                HIPCHK(c, hipStreamSynchronize(c->trace_stream[b]));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                dfree(c->d_samples2[b]); c->samples_bytes2[b] = 0;
+                HIPCHK(c, hipMalloc(&c->d_samples2[b], need));
+                c->samples_bytes2[b] = need;
+            }
+            p.samples = c->d_samples2[b];
+            if (c->inputs_dirty || !c->inputs_recorded)
+            {
+                HIPCHK(c, hipEventRecord(c->ev_inputs, c->stream));
+                c->inputs_dirty = false; c->inputs_recorded = true;
+            }
+            HIPCHK(c, hipStreamWaitEvent(tstream, c->ev_inputs, 0));
+            if (c->acc_pending[b]) HIPCHK(c, hipStreamWaitEvent(tstream, c->ev_acc_done[b], 0));   // buffer b was last read by pass k-2's accumulate
         }
-        p.samples = c->d_samples;
+        else
+        {
+            if (need > c->samples_bytes)
+            {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                dfree(c->d_samples); c->samples_bytes = 0;
+                HIPCHK(c, hipMalloc(&c->d_samples, need));
+                c->samples_bytes = need;
+            }
+            p.samples = c->d_samples;
+        }
         p.first_sample = first + done; p.spp = n;
         p.chunk = chunk; p.num_chunks = num_chunks;
         p.resolve_samples = (float)(first + done + n);
@@ -292,8 +334,8 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         if (items > (1ll << 30)) return fail(c, PTK_ERR_LIMIT, "too many work items in one pass");
         p.num_items = (int)items;
         const int pi = c->last_passes < ptk_ctx::kMaxTimedPasses ? c->last_passes : -1;
-        if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][0], c->stream));
-        p.queues = c->d_queues;
+        if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][0], tstream));
+        p.queues = overlap ? c->d_queues2[b] : c->d_queues;
         if (wavefront)
         {
             const size_t entries = (size_t)tiles * 4 * 64 * (size_t)chunk * num_chunks;
@@ -325,12 +367,23 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
                 rounds = 4;
             }
         }
-        else launch_trace(p, tiles * 4, c->resident_waves, c->stream, stats);
+        else launch_trace(p, tiles * 4, c->resident_waves, tstream, stats);
         HIPCHK(c, hipGetLastError());
-        if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][1], c->stream));
+        if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][1], tstream));
+        if (overlap)
+        {
+            HIPCHK(c, hipEventRecord(c->ev_trace_done[b], tstream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_trace_done[b], 0));
+        }
         launch_accumulate(p, tiles, c->stream);
         HIPCHK(c, hipGetLastError());
         if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][2], c->stream));
+        if (overlap)
+        {
+            HIPCHK(c, hipEventRecord(c->ev_acc_done[b], c->stream));
+            c->acc_pending[b] = true;
+            c->pass_counter++;
+        }
         c->last_passes++; c->last_launches += 2;
         done += n;
     }
@@ -371,6 +424,13 @@ int ptk_create(ptk_ctx** out, int device_ordinal)
     for (int i = 0; i < ptk_ctx::kMaxTimedPasses; i++)
         for (int k = 0; k < 3; k++)
             if (hipEventCreate(&c->ev[i][k]) != hipSuccess) { ptk_destroy(c); return PTK_ERR_HIP; }
+    for (int b = 0; b < 2; b++)
+        if (hipStreamCreateWithFlags(&c->trace_stream[b], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_trace_done[b], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_acc_done[b], hipEventDisableTiming) != hipSuccess ||
+            hipMalloc(&c->d_queues2[b], (8 * PTK_QUEUE_STRIDE + QG_WORDS) * sizeof(unsigned)) != hipSuccess)
+        { ptk_destroy(c); return PTK_ERR_HIP; }
+    if (hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming) != hipSuccess) { ptk_destroy(c); return PTK_ERR_HIP; }
     *out = c;
     return PTK_OK;
 }
@@ -382,6 +442,14 @@ void ptk_destroy(ptk_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_mats); dfree(c->d_lights);
     dfree(c->d_texinfo); dfree(c->d_texels); dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_accum); dfree(c->d_rgb8);
+    for (int b = 0; b < 2; b++)
+    {
+        if (c->trace_stream[b]) { (void)hipStreamSynchronize(c->trace_stream[b]); (void)hipStreamDestroy(c->trace_stream[b]); }
+        if (c->ev_trace_done[b]) (void)hipEventDestroy(c->ev_trace_done[b]);
+        if (c->ev_acc_done[b]) (void)hipEventDestroy(c->ev_acc_done[b]);
+        dfree(c->d_samples2[b]); dfree(c->d_queues2[b]);
+    }
+    if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
     dfree(c->d_exit); dfree(c->d_stats); dfree(c->d_queues); dfree(c->d_samples);
     dfree(c->d_paths); dfree(c->d_cont_q); dfree(c->d_shade_q); dfree(c->d_wq);
     dfree(c->d_live_mask); dfree(c->d_live_list);
@@ -405,6 +473,7 @@ int ptk_set_stream(ptk_ctx* c, void* s)
     if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     c->stream = (hipStream_t)s;
     c->own_stream = false;
+    c->inputs_dirty = true;                      // re-anchor the trace streams behind the new stream
     return PTK_OK;
 }
 
@@ -556,6 +625,7 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
         if (s->materials[s->material[i]].tex[5] >= 0) { c->scene_has_opacity = true; break; }
     c->primary_hit_dirty = true;
     c->have_scene = true;
+    c->inputs_dirty = true;
     return PTK_OK;
 }
 
@@ -818,6 +888,11 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     {
         if (!(value >= 0 && value <= 4096)) return fail(c, PTK_ERR_BAD_ARG, "threshold (lambda in eighths) must be in [0, 4096]");
         (name[0] == 's' ? c->opt_shade_thr : c->opt_gen_thr) = (int)value;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "overlap"))
+    {
+        c->opt_overlap = value != 0.0 ? 1 : 0;
         return PTK_OK;
     }
     if (!std::strcmp(name, "wavefront"))

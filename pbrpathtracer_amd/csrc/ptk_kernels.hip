@@ -1073,14 +1073,23 @@ __global__ __launch_bounds__(PTK_BLOCK) void accumulate_kernel(const RenderParam
     v3 acc = V(P.accum[accidx], P.accum[accidx + 1], P.accum[accidx + 2]);
     const size_t subtile = (size_t)owned * 4 + quad;
     const bool black = P.primary_hit && __float_as_int(P.primary_hit[(size_t)py * P.width + px].x) == PTK_NOHIT;
-    for (int c = 0; c < (black ? 0 : P.num_chunks); c++)
+    if (!black)
     {
-        const float4* in = P.samples + ((subtile * P.num_chunks + c) * P.chunk) * 64 + lane;
-        const uint32_t s_begin = (uint32_t)c * (uint32_t)P.chunk;
-        const uint32_t n = min((uint32_t)P.chunk, P.spp - s_begin);
-        for (uint32_t s = 0; s < n; s++)
+        // the samples of one pixel are a strided array (chunk after chunk of its quadrant's items): sample s sits at
+        // in[s * 64].  Eight loads in flight per lane, added strictly in sample order.
+        const float4* in = P.samples + (subtile * P.num_chunks * P.chunk) * 64 + lane;
+        uint32_t s = 0;
+        for (; s + 8 <= P.spp; s += 8)
         {
-            float4 col = in[(size_t)s * 64];
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = in[(size_t)(s + k) * 64];
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc = add(acc, V(v[k].x, v[k].y, v[k].z));
+        }
+        for (; s < P.spp; s++)
+        {
+            const float4 col = in[(size_t)s * 64];
             acc = add(acc, V(col.x, col.y, col.z));
         }
     }
