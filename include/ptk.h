@@ -170,7 +170,9 @@ int ptk_gather_accum(ptk_ctx* ctx, void* rccl_comm, int root);
  * hit across samples when the camera is a pinhole and the scene has no opacity texture (default 1). */
 int ptk_set_option(ptk_ctx* ctx, const char* name, double value);
 
-/* measurement: HIP-event times (on the context's stream) of the last ptk_render's kernels */
+/* measurement: HIP-event times of the last ptk_render's kernels (per pass, summed).  With the "overlap" option on and
+ * several passes or back-to-back renders in flight, a trace kernel's time includes waiting for the wave slots its
+ * predecessor's tail still holds: set "overlap" 0 for isolated per-launch durations (bench.py does) */
 int ptk_last_render_ms(ptk_ctx* ctx, float* ms, int* launches);
 int ptk_last_kernel_ms(ptk_ctx* ctx, float* trace_ms, float* accumulate_ms);
 int ptk_collect_stats(ptk_ctx* ctx, uint32_t first_sample, uint32_t spp_count, uint64_t seed, ptk_stats* out);

@@ -690,6 +690,7 @@ int ptk_reset(ptk_ctx* c)
     c->samples = 0;
     c->exit_req = 0;
     HIPCHK(c, hipMemsetAsync(c->d_exit, 0, sizeof(uint32_t), c->stream));
+    c->inputs_dirty = true;                      // the trace streams must see the cleared exit flag
     return PTK_OK;
 }
 
@@ -733,6 +734,7 @@ int ptk_collect_stats(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uin
     if (hipMalloc(&scratch8, px * 3) != hipSuccess) { (void)hipFree(scratch); return fail(c, PTK_ERR_HIP, "hipMalloc"); }
     (void)hipMemsetAsync(scratch, 0, px * 3 * sizeof(float), c->stream);
     (void)hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), c->stream);
+    c->inputs_dirty = true;                      // ... and the zeroed counters
     rc = run_passes(c, first_sample, spp_count, seed, true, scratch, scratch8, nullptr, false);
     c->timed = false;
     unsigned long long h[16] = { 0 };
