@@ -1,24 +1,28 @@
 // HIP kernels for gfx950 (CDNA4, wave64): the per-pixel render loop of the reference
 //   PathTracer::RenderFrame -> Trace -> Hit -> {IntersectTriangle, Image::tex2D, DirectIllumimation}
 //   (reference PathTracing/src/pathtracer.cpp:367-822, mesh.cpp:48-59, image.cpp:63-86)
-// as a path-tracing megakernel (trace_kernel: one path per lane, one 8x8 pixel tile x one chunk of
-// samples per wave) followed by a streaming accumulate_kernel.
+// as a path-tracing kernel of persistent waves (trace_kernel: one path per lane) followed by a streaming
+// accumulate_kernel.
 //
 // Design (not a translation of the reference's recursion):
 //   * Trace is iterative: L += T*e; L += T*direct; T *= weight, with the reference's two counters
 //     (depth arms Russian roulette, iter is the hard stop) and its quirks kept.
-//   * Work item = (8x8 pixel tile, chunk of samples): parallel over pixels AND samples, so a frame
-//     with few non-trivial pixels still fills 256 CUs.  Each finished path stores its radiance as
-//     one float4 into a sample buffer in HBM; accumulate_kernel then folds the samples of a pixel
-//     into the float accumulator strictly in sample order (the reference's one-add-per-RenderFrame
-//     semantics, pathtracer.cpp:798-800) and writes the RGB8 resolve.
-//   * A lane is a state machine {GEN, TRAV, SHADE, DONE}.  Every wave iteration takes a 64-bit
-//     ballot per state and runs only the block most lanes are waiting for: the BVH walk keeps
-//     stepping while at least half of the live lanes are traversing (bounce and shadow rays share
-//     the walk; a finished shadow ray rolls straight into the bounce ray), shading / camera-ray
-//     generation run when enough lanes have queued up, and a lane whose path ends starts the next
-//     sample of its pixel ("path regeneration").  Divergent blocks therefore run with full-ish
-//     EXEC masks instead of once per ray.
+//   * Work item = (8x8 pixel quadrant, chunk of samples); work unit = (live pixel of it, sample): parallel over
+//     pixels AND samples, so a frame with few non-trivial pixels still fills 256 CUs.  Units are dealt to
+//     whichever lane needs work; the waves are persistent and pull items from per-XCD queues built over a
+//     device-side list of the quadrants that have live pixels (live_mask_kernel / live_compact_kernel), so all
+//     64 lanes of every wave trace until the launch runs dry.  Each finished path stores its radiance as one
+//     float4 into a sample buffer in HBM; accumulate_kernel then folds the samples of a pixel into the float
+//     accumulator strictly in sample order (the reference's one-add-per-RenderFrame semantics,
+//     pathtracer.cpp:798-800) and writes the RGB8 resolve.
+//   * A lane is a state machine {NEED, GEN, TRAV, SHADE, DONE}.  Every wave iteration takes a 64-bit ballot per
+//     state and runs one block: the BVH walk keeps stepping (node arm every iteration, triangle arm when enough
+//     lanes hold a leaf; bounce and shadow rays share the walk; a finished shadow ray rolls straight into the
+//     bounce ray) until the lane-iterations wasted by lanes parked for shading / a camera ray outweigh the
+//     lanes that block would leave idle.  Divergent blocks therefore run with full-ish EXEC masks instead of
+//     once per ray.  Scenes of <= 16 triangles skip the hierarchy (FLAT: scalar triangle loads, shadow and
+//     bounce ray in one pass).  MODE 1 / 2 compile the same body as the two stages of a wavefront formulation
+//     (evaluated, slower here - DESIGN.md 4.1).
 //   * Closest hit: BVH2 with both child boxes in the 64-byte parent record (left/right planes
 //     interleaved -> packed-f32 slab arithmetic), ordered descent with t-max culling, per-lane stack
 //     in LDS laid out [level][thread] (conflict-free ds_read/write_b32).  Result = min over accepted
