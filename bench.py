@@ -249,10 +249,10 @@ def main():
         from pbrpathtracer_amd.distributed import owned_tile_count
         chunk = 8 if spp * owned_tile_count(W, H, rank, world) * 4.0 / 8.0 >= 49152.0 else 4
         chunk = min(chunk, spp)
-        # counters over a few chunks of the whole frame, with the work-item size the timed launches used
+        # counters over 64 spp of the whole frame, with the work-item size the timed launches used
         ctx.set_tile(0, 1)
         ctx.set_option("chunk", chunk)
-        stats = ctx.collect_stats(0, min(spp, 2 * chunk), args.seed)
+        stats = ctx.collect_stats(0, min(spp, 64), args.seed)         # long enough for the persistent waves' steady state
         ctx.set_option("chunk", 0)
         ctx.set_tile(rank, world)
         flat = ntri_for_chunk <= 16
