@@ -49,7 +49,10 @@ namespace ptk {
 #define PTK_TRACE_BLOCK 64          // trace_kernel: one wave per workgroup -> finest-grained dispatch
 #endif
 #ifndef PTK_TRACE_WAVES
-#define PTK_TRACE_WAVES 4           // waves per SIMD the register allocator must allow (LDS stack: 8 KiB/wave -> 5)
+#define PTK_TRACE_WAVES 4           // waves per SIMD the register allocator must allow, FLAT variant (VALU-bound: more would not help)
+#endif
+#ifndef PTK_TRACE_WAVES_BVH
+#define PTK_TRACE_WAVES_BVH 4       // ... BVH variant
 #endif
 #define PTK_NOHIT 0x7fffffff
 
@@ -381,7 +384,7 @@ enum : int { WQ_CONT_HEAD = 0, WQ_CONT_TAIL = 32, WQ_SHADE_HEAD = 64, WQ_SHADE_T
 enum : uint32_t { WQ_BLOCK = 256u, WQ_NONE = 0xffffffffu };    // queue entries reserved / popped per atomic; an unused entry
 
 template <bool STATS, bool FLAT, int MODE>
-__global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES) void trace_kernel(const RenderParams P)
+__global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRACE_WAVES_BVH)) void trace_kernel(const RenderParams P)
 {
     static_assert(MODE == MODE_MEGA || !FLAT, "the wavefront stages exist for the BVH walk only");
     __shared__ int lds_stack[(FLAT || MODE == MODE_SHADE) ? 1 : PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
@@ -1251,6 +1254,7 @@ void launch_trace(const RenderParams& p0, int num_subtiles, int resident_waves, 
     geo.w[QG_TILES_X] = p.tiles_x; geo.w[QG_CHUNK] = p.chunk; geo.w[QG_SPP] = (int)p.spp;
     // big launches: persistent waves, as many one-wave workgroups as the chip holds at once, each pulling items until
     // none is left; small ones: a wave per (possible) item, the dispatcher balances those better
+    if (!(p.flat_count > 0) && PTK_TRACE_WAVES_BVH != 4) resident_waves = resident_waves / 16 * 4 * PTK_TRACE_WAVES_BVH;
     if (p.persistent < 0) p.persistent = padded > 4 * resident_waves ? 1 : 0;
     const int generations = p.persistent ? std::max(1, std::min(p.generations, padded / resident_waves)) : 1;
     const int blocks = p.persistent ? resident_waves * generations : padded;
