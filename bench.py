@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--force-exchange", action="store_true", help="run the exchange step even at N=1 (rehearsal of the N>1 path)")
     ap.add_argument("--opts", default=os.environ.get("PTK_OPTS", ""), help="ptk_set_option pairs, k=v[,k=v...] (tuning experiments)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = REHEARSAL of the N>1 control flow where ranks must share one GPU (RCCL refuses that): the exchange "
+                         "then goes through host copies; the numbers mean nothing")
     ap.add_argument("--share-of", type=int, default=0, help="rehearsal: render only rank 0's tiles of an N-rank split on this one GPU")
     args = ap.parse_args()
 
@@ -133,8 +136,14 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the render path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    rehearsal = args.backend == "gloo"
+    if rehearsal:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 and rehearsal:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         try:
             # RCCL's own stream at high priority: the collective's workgroups get the wave slots that retiring
@@ -179,11 +188,15 @@ def main():
     ctx.reset()
 
     from pbrpathtracer_amd.distributed import AccumulatorExchange
-    exchange = AccumulatorExchange(accum, dst=0, width=W, height=H) if (world > 1 or args.force_exchange) else None
+    host_accum = torch.zeros(H * W * 3, dtype=torch.float32) if rehearsal else None
+    exchange = AccumulatorExchange(host_accum if rehearsal else accum, dst=0, width=W, height=H) if (world > 1 or args.force_exchange) else None
 
     def step(first):
         ctx.render(first, spp, args.seed)
-        if exchange is not None:
+        if exchange is not None and rehearsal:
+            host_accum.copy_(accum)                 # (synchronises; rehearsal only)
+            exchange.start()
+        elif exchange is not None:
             # snapshot + RCCL reduce on a side stream: the collective of step k overlaps the trace
             # kernel of step k+1 (tiles of other ranks are exact zeros, so the sum is a gather)
             exchange.start()
@@ -204,7 +217,7 @@ def main():
         except Exception as e:                              # pragma: no cover - depends on the installed collectives
             if rank == 0:
                 print(f"bench.py: packed exchange unavailable ({type(e).__name__}: {e}); using reduce", file=sys.stderr)
-            exchange = AccumulatorExchange(accum, dst=0, mode="reduce")
+            exchange = AccumulatorExchange(host_accum if rehearsal else accum, dst=0, mode="reduce")
     for _ in range(args.warmup):
         step(first); first += spp
     fence()
@@ -216,8 +229,17 @@ def main():
             pass
     fence()
     elapsed = time.perf_counter() - t0
+    if rehearsal and world > 1 and exchange is not None:
+        # property check of the exchange: the gathered image holds exactly what the ranks hold together
+        part = torch.tensor([float(accum.double().sum().item())], dtype=torch.float64)
+        dist.all_reduce(part, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            got = float(exchange.result.double().sum().item())
+            ok = abs(got - float(part.item())) <= 1e-9 * max(1.0, abs(got))
+            print(f"bench.py rehearsal: gathered-image checksum {'OK' if ok else 'MISMATCH'} ({got:.6f} vs {float(part.item()):.6f}), "
+                  f"exchange mode {exchange.mode}", file=sys.stderr)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

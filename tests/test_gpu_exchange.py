@@ -103,3 +103,25 @@ def test_torch_distributed_path_world_1():
         c.close(); c2.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py's N > 1 control flow (one process per rank, tile split, packed exchange, barrier + max-over-ranks timing,
+    one JSON line from rank 0) with two ranks sharing this box's one GPU: RCCL refuses two ranks on one device, so the
+    rehearsal backend (gloo, exchange through host copies) stands in; the gathered image must hold exactly what the two
+    ranks hold together."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--config", "C1", "--backend", "gloo", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "gathered-image checksum OK" in r.stderr, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["parallelism"] == "tile-split x2" and "gather" in d["config"]["exchange"]
