@@ -177,3 +177,32 @@ def test_page_locked_handoff_buffer(tmp_path):
         pt.SetOutImage(None)
         del out, pt
     assert frames[0].any() and np.array_equal(frames[0], frames[1])
+
+
+@pytest.mark.parametrize("cfg,world", [("C2", 97), ("C3", 149), ("C4", 499), ("C5", 1999)])
+def test_full_size_spot_check_against_oracle(tmp_path, oracle_mod, cfg, world):
+    """The BASELINE configs at their FULL size and sample count (persistent waves, live-quadrant list, two passes for
+    C4): the oracle renders the tiles of one rank of a `world`-way split (a few dozen of the frame's tiles, spread
+    over it) and the GPU's accumulator must equal it there bit for bit."""
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd import distributed as D
+    from pbrpathtracer_amd.pathtracer import PathTracer
+    pts, scene, spp = S.build_config(cfg, str(tmp_path))
+    from pbrpathtracer_amd.pathtracer import camera_from_scene
+    pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(21)
+    cam = camera_from_scene(scene)
+    if scene.pinhole:
+        pt.SetCameraAperture(0.0)               # as bench.py does (the .pts carries F = 1e9)
+        cam["aperture"] = 0.0
+    W, H = pt.GetResolution(); Dp = pt.GetTraceDepth()
+    pt.RenderFrames(spp)
+    assert pt.LastError() == "" and pt.GetSamples() == spp
+    got = pt.ReadAccumulation()
+    o = oracle_mod.Oracle(pt.StagedScene())
+    ocam = oracle_mod.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+    rank = world // 3
+    ref, _ = o.render(ocam, W, H, Dp, 0, spp, 21, rank=rank, world=world, want_rgb8=False)
+    mask = D.tile_owner_mask(W, H, rank, world)[::-1]           # accumulator rows are bottom-up
+    assert mask.sum() >= 16 * 16 * 4 and ref[mask].any()
+    assert np.array_equal(got[mask], ref[mask])
+    pt.close()
