@@ -292,6 +292,62 @@ __device__ __forceinline__ bool tri_test(const PT& P, Walk& W, float4 t0, float4
     return ok & (W.occl_tri >= 0) & (tri != W.occl_tri) & (t < W.occl_limit);
 }
 
+// FLAT pass, both rays of a lane against one triangle in PACKED f32: x = the bounce ray (W), y = the shadow ray (WS).
+// Every Moeller-Trumbore operation is the same IEEE mul / add / sub as in tri_test, on two values at once
+// (v_pk_mul_f32 / v_pk_add_f32 run at the rate of their scalar forms; the triangle's words come from SGPRs), which
+// nearly halves the instructions of the hottest loop of the Cornell configs.  No early returns: all quantities are
+// computed and the reference's tests AND-ed in their negated form, exactly as tri_test does.  Returns true when the
+// shadow ray has been decided by an occluder.
+struct RayPair { f2 ox, oy, oz, dx, dy, dz; };
+
+template <bool STATS, class PT>
+__device__ __forceinline__ bool tri_test_pair(const PT& P, Walk& W, Walk& WS, const RayPair& R, const bool shadow_live, float4 t0, float4 t1,
+                                              float4 t2, const Rng& rng, uint32_t ray_bounce, uint32_t ray_shadow, Counters& cnt)
+{
+    if (STATS) cnt.tris += shadow_live ? 2u : 1u;
+    const float v0x = t0.x, v0y = t0.y, v0z = t0.z, e1x = t0.w, e1y = t1.x, e1z = t1.y, e2x = t1.z, e2y = t1.w, e2z = t2.x;
+    // h = cross(rd, edge2)
+    const f2 hx = R.dy * e2z - R.dz * e2y, hy = R.dz * e2x - R.dx * e2z, hz = R.dx * e2y - R.dy * e2x;
+    const f2 a = hx * e1x + hy * e1y + hz * e1z;                 // dot(edge1, h)
+    const f2 f = { 1.0f / a.x, 1.0f / a.y };
+    const f2 sx = R.ox - v0x, sy = R.oy - v0y, sz = R.oz - v0z;  // s = ro - v0
+    const f2 u = f * (sx * hx + sy * hy + sz * hz);
+    // q = cross(s, edge1)
+    const f2 qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;
+    const f2 v = f * (R.dx * qx + R.dy * qy + R.dz * qz);
+    const f2 t = f * (qx * e2x + qy * e2y + qz * e2z);
+    const f2 uv = u + v;
+    const int tri = __float_as_int(t2.y);
+    const int otex = __float_as_int(t2.z);
+    bool okb = !(fabsf(a.x) < PTK_EPS) & !(u.x < 0.0f) & !(u.x > 1.0f) & !(v.x < 0.0f) & !(uv.x > 1.0f) & (t.x > PTK_EPS);
+    bool oks = !(fabsf(a.y) < PTK_EPS) & !(u.y < 0.0f) & !(u.y > 1.0f) & !(v.y < 0.0f) & !(uv.y > 1.0f) & (t.y > PTK_EPS);
+    okb = okb & ((t.x < W.best.t) | ((t.x == W.best.t) & (tri < W.best.tri)));
+    oks = oks & shadow_live & ((t.y < WS.best.t) | ((t.y == WS.best.t) & (tri < WS.best.tri)));
+    if ((okb | oks) && otex >= 0)
+    {
+        // stochastic opacity, pathtracer.cpp:469-476 (GetUV :533-536); rare: skipped with s_cbranch_execz
+        const float4* sp4 = P.shade + (size_t)tri * SHADE_F4;
+        const float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
+        if (okb)
+        {
+            const float w = 1.0f - u.x - v.x;
+            const float op = tex2d_r(P, otex, w * s1.x + u.x * s1.z + v.x * s2.x, w * s1.y + u.x * s1.w + v.x * s2.y);
+            if (STATS) cnt.tex++;
+            okb = rng.opacity(ray_bounce, (uint32_t)tri) < op;
+        }
+        if (oks)
+        {
+            const float w = 1.0f - u.y - v.y;
+            const float op = tex2d_r(P, otex, w * s1.x + u.y * s1.z + v.y * s2.x, w * s1.y + u.y * s1.w + v.y * s2.y);
+            if (STATS) cnt.tex++;
+            oks = rng.opacity(ray_shadow, (uint32_t)tri) < op;
+        }
+    }
+    W.best.tri = okb ? tri : W.best.tri; W.best.t = okb ? t.x : W.best.t; W.best.u = okb ? u.x : W.best.u; W.best.v = okb ? v.x : W.best.v;
+    WS.best.tri = oks ? tri : WS.best.tri; WS.best.t = oks ? t.y : WS.best.t; WS.best.u = oks ? u.y : WS.best.u; WS.best.v = oks ? v.y : WS.best.v;
+    return oks & (tri != WS.occl_tri) & (t.y < WS.occl_limit);
+}
+
 // One BVH step of a lane: up to TWO units of work - one triangle of the pending leaf (arm A) AND one
 // interior node (arm B).  A leaf reached by arm B is parked in the lane's one-entry triangle queue and the
 // descent continues with the next node from the stack, so the two arms overlap instead of alternating
@@ -719,13 +775,15 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                     const bool shadow = WS.occl_tri >= 0;
                     const uint32_t bounce_ray = shadow ? ray + 1u : ray;
                     bool stop = !shadow;
+                    RayPair R;
+                    R.ox = f2{ W.ro.x, WS.ro.x }; R.oy = f2{ W.ro.y, WS.ro.y }; R.oz = f2{ W.ro.z, WS.ro.z };
+                    R.dx = f2{ W.rd.x, WS.rd.x }; R.dy = f2{ W.rd.y, WS.rd.y }; R.dz = f2{ W.rd.z, WS.rd.z };
                     for (int k = 0; k < P.flat_count; k++)
                     {
                         const f4v a0 = ct[k * TRI_F4], a1 = ct[k * TRI_F4 + 1], a2 = ct[k * TRI_F4 + 2];
                         const float4 t0 = make_float4(a0.x, a0.y, a0.z, a0.w), t1 = make_float4(a1.x, a1.y, a1.z, a1.w),
                                      t2 = make_float4(a2.x, a2.y, a2.z, a2.w);
-                        (void)tri_test_early<STATS>(P, W, t0, t1, t2, rng, bounce_ray, cnt);
-                        if (!stop) stop = tri_test_early<STATS>(P, WS, t0, t1, t2, rng, ray, cnt);
+                        stop |= tri_test_pair<STATS>(P, W, WS, R, !stop, t0, t1, t2, rng, bounce_ray, ray, cnt);
                     }
                     if (shadow)
                     {
