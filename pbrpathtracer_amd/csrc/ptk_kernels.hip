@@ -207,47 +207,6 @@ struct Walk {
 // Candidate test of one triangle record: Hit's leaf branch (pathtracer.cpp:463-489) = Moeller-Trumbore
 // + order-independent closest rule + stochastic opacity.  Returns true when the walk can stop (an
 // occluder decided a shadow ray).
-// FLAT pass variant with the reference's early returns: there the whole wave tests the same triangle, so
-// a rejection usually holds for every lane and the branch skips real work.
-template <bool STATS, class PT>
-__device__ __forceinline__ bool tri_test_early(const PT& P, Walk& W, float4 t0, float4 t1, float4 t2, const Rng& rng,
-                                               uint32_t ray, Counters& cnt)
-{
-    const v3 ro = W.ro, rd = W.rd;
-    if (STATS) cnt.tris++;
-    v3 v0 = V(t0.x, t0.y, t0.z);
-    v3 edge1 = V(t0.w, t1.x, t1.y);
-    v3 edge2 = V(t1.z, t1.w, t2.x);
-    v3 h = cross(rd, edge2);
-    float a = dot(edge1, h);
-    if (fabsf(a) < PTK_EPS) return false;
-    float f = 1.0f / a;
-    v3 s = sub(ro, v0);
-    float u = f * dot(s, h);
-    if (u < 0.0f || u > 1.0f) return false;
-    v3 q = cross(s, edge1);
-    float v = f * dot(rd, q);
-    if (v < 0.0f || u + v > 1.0f) return false;
-    float t = f * dot(edge2, q);
-    if (!(t > PTK_EPS)) return false;
-    int tri = __float_as_int(t2.y);
-    if (!(t < W.best.t || (t == W.best.t && tri < W.best.tri))) return false;
-    int otex = __float_as_int(t2.z);
-    if (otex >= 0)
-    {
-        const float4* sp4 = P.shade + (size_t)tri * SHADE_F4;
-        float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
-        float w = 1.0f - u - v;
-        float ux = w * s1.x + u * s1.z + v * s2.x;
-        float uy = w * s1.y + u * s1.w + v * s2.y;
-        float op = tex2d_r(P, otex, ux, uy);
-        if (STATS) cnt.tex++;
-        if (!(rng.opacity(ray, (uint32_t)tri) < op)) return false;
-    }
-    W.best.tri = tri; W.best.t = t; W.best.u = u; W.best.v = v;
-    return W.occl_tri >= 0 && tri != W.occl_tri && t < W.occl_limit;
-}
-
 template <bool STATS, class PT>
 __device__ __forceinline__ bool tri_test(const PT& P, Walk& W, float4 t0, float4 t1, float4 t2, const Rng& rng,
                                          uint32_t ray, Counters& cnt)
