@@ -44,6 +44,8 @@ struct ptk_ctx {
     int width = 0, height = 0, max_depth = 3;                                 // pathtracer.cpp:15
     float4* d_primary = nullptr;
     float4* d_primary_hit = nullptr;  // primary-visibility cache (pinhole, no opacity textures)
+    uint2* d_pixel_rng = nullptr;     // per pixel: (pixel key, PCG increment) for pixel_rng_seed
+    uint64_t pixel_rng_seed = 0; bool pixel_rng_valid = false;
     bool primary_hit_dirty = true, scene_has_opacity = false;
     int opt_primary_cache = 1;
     int opt_flat_shade_w = 8, opt_flat_gen_w = 64;
@@ -247,6 +249,14 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         }
         p.primary_hit = c->d_primary_hit;
     }
+    if (!c->pixel_rng_valid || c->pixel_rng_seed != seed)
+    {
+        launch_pixel_rng((uint32_t)seed, (uint32_t)(seed >> 32), c->width * c->height, c->d_pixel_rng, c->stream);
+        HIPCHK(c, hipGetLastError());
+        c->pixel_rng_seed = seed; c->pixel_rng_valid = true;
+        c->inputs_dirty = true;
+    }
+    p.pixel_rng = c->d_pixel_rng;
     const int tiles = owned_tiles(p);
     c->last_passes = 0; c->last_launches = 0;
     if (tiles == 0) return PTK_OK;
@@ -442,6 +452,7 @@ void ptk_destroy(ptk_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_mats); dfree(c->d_lights);
     dfree(c->d_texinfo); dfree(c->d_texels); dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_accum); dfree(c->d_rgb8);
+    dfree(c->d_pixel_rng);
     for (int b = 0; b < 2; b++)
     {
         if (c->trace_stream[b]) { (void)hipStreamSynchronize(c->trace_stream[b]); (void)hipStreamDestroy(c->trace_stream[b]); }
@@ -656,10 +667,12 @@ int ptk_set_frame(ptk_ctx* c, int width, int height, int max_depth)
     if (width != c->width || height != c->height || !c->d_accum)
     {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_accum); dfree(c->d_rgb8);
+        dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_accum); dfree(c->d_rgb8); dfree(c->d_pixel_rng);
+        c->pixel_rng_valid = false;
         size_t px = (size_t)width * height;
         HIPCHK(c, hipMalloc(&c->d_primary, px * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->d_primary_hit, px * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_pixel_rng, px * sizeof(uint2)));
         HIPCHK(c, hipMalloc(&c->d_accum, px * 3 * sizeof(float)));
         HIPCHK(c, hipMalloc(&c->d_rgb8, px * 3));
         c->width = width; c->height = height;

@@ -75,6 +75,7 @@ struct RenderParams {
     const int4* texinfo;        // (width, height, first texel index, 0)
     const uint32_t* texels;     // RGBA8 atlas as packed words (r = low byte)
     const float4* primary;      // [H][W] unit primary directions before DOF (top-down rows)
+    const uint2* pixel_rng;     // [H][W] (pixel key, PCG increment) of the pixel's RNG streams for this launch's seed
     const float4* primary_hit;  // [H][W] (bits tri | PTK_NOHIT, t, u, v) of the camera ray, or null when not cacheable
     float* accum;               // [H][W][3] float RGB, rows bottom-up (mTotalImg)
     uint8_t* rgb8;              // [H][W][3] RGB8, rows bottom-up (mOutImg)
@@ -116,6 +117,7 @@ struct ProbeParams {
 
 void launch_trace(const RenderParams& p, int num_subtiles, int resident_waves, hipStream_t stream, bool stats);
 void launch_wavefront(const RenderParams& p, int num_subtiles, int cus, int rounds, bool first, hipStream_t stream, bool stats);
+void launch_pixel_rng(uint32_t seed_lo, uint32_t seed_hi, int n, uint2* out, hipStream_t stream);
 void launch_live_list(const RenderParams& p, int num_subtiles, unsigned long long* mask, unsigned* list, unsigned* count, hipStream_t stream);
 void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t stream);
 void launch_primary(const PrimaryParams& p, hipStream_t stream);

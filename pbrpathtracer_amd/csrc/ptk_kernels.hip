@@ -1013,8 +1013,11 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
             if (st == ST_GEN)
             {
                 // ---- camera ray with thin-lens DOF, pathtracer.cpp:785-791 + SampleCircle :734-739 ----
-                const uint32_t pkey = pixel_key(P.seed_lo, P.seed_hi, pix);
-                rng.inc = (hash32(pkey ^ 0x9E3779B9u) << 1) | 1u;
+                // the pixel's RNG stream constants (pixel_key, increment) come from a per-frame table: they depend on
+                // (seed, pixel) only, and four of the five hashes of a path's start went into them
+                const uint2 pr = P.pixel_rng[pix];
+                const uint32_t pkey = pr.x;
+                rng.inc = pr.y;
                 rng.state = hash32(P.first_sample + sample_abs + pkey);
                 rng.key = rng.state;
                 // per-pixel constants are re-read here (L1/L2 hits) instead of living in registers
@@ -1247,6 +1250,18 @@ __global__ __launch_bounds__(1024) void live_compact_kernel(const unsigned long 
         __syncthreads();
     }
     if (t == 0) *count = base;
+}
+
+__global__ __launch_bounds__(PTK_BLOCK) void pixel_rng_kernel(uint32_t seed_lo, uint32_t seed_hi, int n, uint2* out)
+{
+    const int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pkey = pixel_key(seed_lo, seed_hi, (uint32_t)i);
+    out[i] = make_uint2(pkey, (hash32(pkey ^ 0x9E3779B9u) << 1) | 1u);
+}
+void launch_pixel_rng(uint32_t seed_lo, uint32_t seed_hi, int n, uint2* out, hipStream_t stream)
+{
+    if (n > 0) hipLaunchKernelGGL(pixel_rng_kernel, dim3((n + PTK_BLOCK - 1) / PTK_BLOCK), dim3(PTK_BLOCK), 0, stream, seed_lo, seed_hi, n, out);
 }
 
 void launch_live_list(const RenderParams& p, int num_subtiles, unsigned long long* mask, unsigned* list, unsigned* count, hipStream_t stream)
