@@ -334,6 +334,17 @@ def tier_k_images(ref: Ref, tmp: str):
     add("jpg_prog_grey", PI.fromarray(grey, "L"), "JPEG", quality=70, progressive=True)
     add("jpg_prog_odd_17x9", PI.fromarray(base[:9, :17], "RGB"), "JPEG", quality=85, subsampling=2, progressive=True)
     add("jpg_prog_restart", rgb, "JPEG", quality=75, subsampling=2, progressive=True, restart_marker_blocks=3)
+    # four components (print workflows): CMYK as Pillow writes it (Adobe APP14, transform 0), the same stream relabelled
+    # YCCK (transform 2) and with the Adobe marker cut out (stb then reads YCbCr and ignores the fourth plane)
+    cmyk = PI.fromarray(np.dstack([base, ((xx * 3 + yy * 2) % 256).astype(np.uint8)]), "CMYK")
+    add("jpg_cmyk_q85", cmyk, "JPEG", quality=85)
+    add("jpg_cmyk_prog", cmyk, "JPEG", quality=70, progressive=True)
+    raw = cases[-2][1]
+    k = raw.find(b"\xff\xee")
+    assert k > 0 and raw[k + 4:k + 9] == b"Adobe" and raw[k + 15] == 0
+    cases.append(("jpg_ycck_relabelled", raw[:k + 15] + b"\x02" + raw[k + 16:]))
+    seg = 2 + ((raw[k + 2] << 8) | raw[k + 3])
+    cases.append(("jpg_4comp_no_adobe", raw[:k] + raw[k + seg:]))
     add("png_rgb", rgb, "PNG")
     add("png_rgba", PI.fromarray(np.dstack([base, (xx * 4 % 256).astype(np.uint8)]), "RGBA"), "PNG")
     add("png_grey", PI.fromarray(grey, "L"), "PNG")

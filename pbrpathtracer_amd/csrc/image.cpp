@@ -3,7 +3,7 @@
 // decoded once to RGBA8 and uploaded into the device texel atlas by PathTracer::BuildBVH.
 //
 // Formats: BMP and TGA (every variant stb_image 2.27 accepts), binary PNM (P5 / P6, maxval <= 255 or 16-bit), PNG incl. Adam7 interlace and colour-key tRNS (colour types 0, 2, 3, 4, 6;
-// bit depths 1-16) through zlib, and baseline / extended-sequential / progressive Huffman JPEG (grey, YCbCr, RGB).  Everything is expanded to 4 channels the way stbi_load(..., 4)
+// bit depths 1-16) through zlib, and baseline / extended-sequential / progressive Huffman JPEG (grey, YCbCr, RGB, CMYK, YCCK).  Everything is expanded to 4 channels the way stbi_load(..., 4)
 // does (grey -> g,g,g,255; 16-bit -> high byte).  Images with a side > 1024 are reduced so the
 // longest side is 1024 (image.cpp:47-60) with stb_image_resize's default downsampling (Mitchell kernel,
 // clamped edges), bit-identically (tests/golden/tier_k_resize.npz).
@@ -711,7 +711,7 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
             z.h = z.get16(); z.w = z.get16();
             if (z.w <= 0 || z.h <= 0 || z.w > (1 << 14) || z.h > (1 << 14)) return false;
             z.ncomp = z.get8();
-            if (z.ncomp != 1 && z.ncomp != 3) return false;       // CMYK / YCCK not supported
+            if (z.ncomp != 1 && z.ncomp != 3 && z.ncomp != 4) return false;
             if (Lf != 8 + 3 * z.ncomp) return false;
             z.rgb = 0;
             for (int i = 0; i < z.ncomp; i++)
@@ -860,7 +860,7 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
     const bool is_rgb = z.ncomp == 3 && (z.rgb == 3 || (z.app14 == 0 && !z.jfif));
     rgba.resize((size_t)w * h * 4);
     struct Res { int hs, vs, ystep, w_lores, ypos; const unsigned char *line0, *line1; std::vector<unsigned char> buf;
-                 const unsigned char* (*fn)(unsigned char*, const unsigned char*, const unsigned char*, int, int); } res[3];
+                 const unsigned char* (*fn)(unsigned char*, const unsigned char*, const unsigned char*, int, int); } res[4];
     for (int k = 0; k < z.ncomp; k++)
     {
         Res& r = res[k];
@@ -871,7 +871,9 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
         r.fn = (r.hs == 1 && r.vs == 1) ? jres_1 : (r.hs == 1 && r.vs == 2) ? jres_v2 : (r.hs == 2 && r.vs == 1) ? jres_h2
              : (r.hs == 2 && r.vs == 2) ? jres_hv2 : jres_generic;
     }
-    const unsigned char* co[3] = { 0, 0, 0 };
+    const unsigned char* co[4] = { 0, 0, 0, 0 };
+    // 0..255 * 0..255 -> 0..255, rounded (stb_image.h:3805-3809): the K channel of CMYK / YCCK files
+    auto mul8 = [](unsigned x, unsigned y) -> unsigned char { unsigned t = x * y + 128; return (unsigned char)((t + (t >> 8)) >> 8); };
     for (int j = 0; j < h; j++)
     {
         unsigned char* out = &rgba[(size_t)j * w * 4];
@@ -887,8 +889,17 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
                 if (++r.ypos < z.comp[k].y) r.line1 += z.comp[k].w2;
             }
         }
-        if (z.ncomp == 3 && !is_rgb)
+        const bool ycc = (z.ncomp == 3 && !is_rgb) || (z.ncomp == 4 && z.app14 != 0);     // 4 components: Adobe transform 2 = YCCK, other = YCbCr + ignored 4th
+        if (z.ncomp == 4 && z.app14 == 0)                          // CMYK (stb_image.h:3903-3911)
+            for (int i = 0; i < w; i++)
+            {
+                const unsigned m = co[3][i];
+                out[0] = mul8(co[0][i], m); out[1] = mul8(co[1][i], m); out[2] = mul8(co[2][i], m); out[3] = 255;
+                out += 4;
+            }
+        else if (ycc)
         {
+            unsigned char* row = out;
             for (int i = 0; i < w; i++)                            // stbi__YCbCr_to_RGB_row
             {
                 int y_fixed = (co[0][i] << 20) + (1 << 19);
@@ -902,6 +913,12 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
                 out[0] = jclamp(r); out[1] = jclamp(g); out[2] = jclamp(b); out[3] = 255;
                 out += 4;
             }
+            if (z.ncomp == 4 && z.app14 == 2)                      // YCCK (stb_image.h:3912-3921)
+                for (int i = 0; i < w; i++, row += 4)
+                {
+                    const unsigned m = co[3][i];
+                    row[0] = mul8(255u - row[0], m); row[1] = mul8(255u - row[1], m); row[2] = mul8(255u - row[2], m);
+                }
         }
         else if (z.ncomp == 3)
             for (int i = 0; i < w; i++) { out[0] = co[0][i]; out[1] = co[1][i]; out[2] = co[2][i]; out[3] = 255; out += 4; }
