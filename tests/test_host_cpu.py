@@ -287,3 +287,20 @@ def test_large_textures_reduce_like_stb_image_resize(tmp_path):
         assert got is not None and got.shape == exp.shape, (name, None if got is None else got.shape, exp.shape)
         assert max(got.shape[0], got.shape[1]) == 1024
         assert np.array_equal(got, exp), (name, int((got != exp).sum()))
+
+
+def _build_dropin_example(tmp_path):
+    exe = str(tmp_path / "dropin_render_loop")
+    libdir = os.path.join(ROOT, "pbrpathtracer_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "dropin_render_loop.cpp"),
+                           "-L" + libdir, "-lptk", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_dropin_header_compiles_and_links_natively(tmp_path):
+    """include/pathtracer.h + libptk.so serve a plain C++ translation unit written like the reference's render loop
+    (tests/cpp/dropin_render_loop.cpp): it compiles with g++ alone (no HIP, no GL, no glm install) and links."""
+    exe = _build_dropin_example(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 2 and "usage" in out.stderr
