@@ -401,6 +401,18 @@ def tier_k_images(ref: Ref, tmp: str):
     add("png_rgb_key", rgb, "PNG", transparency=tuple(int(v) for v in base[7, 9]))
     cases.append(("png_grey4_key", png_manual((b19[..., :1] // 16), 4, 0, trns=struct.pack(">H", 7))))
 
+    # ---- GIF (first frame): interlaced and not, transparency index, a frame smaller than the logical screen with a
+    # background index > 0 (header patched by hand: Pillow always covers the screen)
+    pq = rgb.quantize(64)
+    add("gif_interlaced", pq, "GIF", interlace=1)
+    add("gif_plain", pq, "GIF", interlace=0)
+    add("gif_transparent", pq, "GIF", interlace=0, transparency=5)
+    add("gif_grey", PI.fromarray(grey, "L"), "GIF")
+    add("gif_1x1", PI.fromarray(base[:1, :1], "RGB").quantize(2), "GIF")
+    g = bytearray(cases[-4][1])                                      # gif_plain: 53 x 37
+    g[6:8] = struct.pack("<H", 60); g[8:10] = struct.pack("<H", 41); g[11] = 7     # screen 60 x 41, background index 7
+    cases.append(("gif_small_frame_bg", bytes(g)))
+
     # ---- BMP / TGA (the reference's texture dialog offers them, main.cpp:849): Pillow's writers plus
     # hand-packed headers for the variants Pillow cannot produce
     small = base[:11, :13]

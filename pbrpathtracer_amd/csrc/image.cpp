@@ -2,7 +2,7 @@
 // on stb_image / stb_image_resize) with a small own decoder.  Off the per-sample path: images are
 // decoded once to RGBA8 and uploaded into the device texel atlas by PathTracer::BuildBVH.
 //
-// Formats: BMP and TGA (every variant stb_image 2.27 accepts), binary PNM (P5 / P6, maxval <= 255 or 16-bit), PNG incl. Adam7 interlace and colour-key tRNS (colour types 0, 2, 3, 4, 6;
+// Formats: BMP and TGA (every variant stb_image 2.27 accepts), GIF (first frame), binary PNM (P5 / P6, maxval <= 255 or 16-bit), PNG incl. Adam7 interlace and colour-key tRNS (colour types 0, 2, 3, 4, 6;
 // bit depths 1-16) through zlib, and baseline / extended-sequential / progressive Huffman JPEG (grey, YCbCr, RGB, CMYK, YCCK).  Everything is expanded to 4 channels the way stbi_load(..., 4)
 // does (grey -> g,g,g,255; 16-bit -> high byte).  Images with a side > 1024 are reduced so the
 // longest side is 1024 (image.cpp:47-60) with stb_image_resize's default downsampling (Mitchell kernel,
@@ -1108,6 +1108,155 @@ bool decode_bmp(const std::vector<unsigned char>& d, int& w, int& h, std::vector
     return true;
 }
 
+// ---- GIF: the first frame, as stbi_load(..., 4) returns it (stb_image.h:6502-6997) ----------------------
+// LZW raster with stb's code-table rules, interlaced rows, the graphic-control transparency index, pixels of the
+// logical screen the frame does not cover filled with the background entry when its index is > 0 - copied in the
+// palette's B,G,R byte order, as stb does.
+bool decode_gif(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgba)
+{
+    LeReader r(d);
+    if (r.u8() != 'G' || r.u8() != 'I' || r.u8() != 'F' || r.u8() != '8') return false;
+    const int version = r.u8();
+    if ((version != '7' && version != '9') || r.u8() != 'a') return false;
+    const int gw = r.u16(), gh = r.u16();
+    const int flags = r.u8(), bgindex = r.u8();
+    r.u8();                                                           // aspect ratio
+    if (gw <= 0 || gh <= 0 || gw > (1 << 24) || gh > (1 << 24) || (size_t)gw * gh > ((size_t)1 << 28)) return false;
+    unsigned char pal[256][4], lpal[256][4];                          // B, G, R, A
+    std::memset(pal, 0, sizeof(pal)); std::memset(lpal, 0, sizeof(lpal));
+    auto read_table = [&](unsigned char t[256][4], int n, int transp) {
+        for (int i = 0; i < n; i++)
+        {
+            t[i][2] = (unsigned char)r.u8(); t[i][1] = (unsigned char)r.u8(); t[i][0] = (unsigned char)r.u8();
+            t[i][3] = transp == i ? 0 : 255;
+        }
+    };
+    if (flags & 0x80) read_table(pal, 2 << (flags & 7), -1);
+    std::vector<unsigned char> out((size_t)gw * gh * 4, 0), touched((size_t)gw * gh, 0);
+    int transparent = -1, eflags = 0;
+    for (;;)
+    {
+        const int tag = r.u8();
+        if (tag == 0x21)                                              // extension
+        {
+            const int ext = r.u8();
+            if (ext == 0xF9)                                          // graphic control
+            {
+                const int len = r.u8();
+                if (len == 4)
+                {
+                    eflags = r.u8(); r.u16();
+                    if (transparent >= 0) pal[transparent][3] = 255;
+                    if (eflags & 1) { transparent = r.u8(); pal[transparent][3] = 0; }
+                    else { r.skip(1); transparent = -1; }
+                }
+                else { r.skip(len); continue; }
+            }
+            for (int len; (len = r.u8()) != 0;) r.skip(len);
+            continue;
+        }
+        if (tag != 0x2C) return false;                                // 0x3B (no image at all) or garbage
+        const int x = r.u16(), y = r.u16(), fw = r.u16(), fh = r.u16();
+        if (x + fw > gw || y + fh > gh) return false;
+        const long line = (long)gw * 4;
+        const long start_x = (long)x * 4, start_y = (long)y * line, max_x = start_x + (long)fw * 4, max_y = start_y + (long)fh * line;
+        long cur_x = start_x, cur_y = fw == 0 ? max_y : start_y;
+        const int lflags = r.u8();
+        long step = (lflags & 0x40) ? 8 * line : line;
+        int parse = (lflags & 0x40) ? 3 : 0;
+        const unsigned char (*table)[4];
+        if (lflags & 0x80) { read_table(lpal, 2 << (lflags & 7), (eflags & 1) ? transparent : -1); table = lpal; }
+        else if (flags & 0x80) table = pal;
+        else return false;
+        // ---- LZW raster
+        const int lzw_cs = r.u8();
+        if (lzw_cs > 12) return false;
+        struct Code { short prefix; unsigned char first, suffix; };
+        std::vector<Code> codes(8192);
+        const int clear = 1 << lzw_cs;
+        bool first = true;
+        int codesize = lzw_cs + 1, codemask = (1 << codesize) - 1, bits = 0, valid_bits = 0, avail = clear + 2, oldcode = -1, len = 0;
+        for (int c = 0; c < clear; c++) { codes[c].prefix = -1; codes[c].first = (unsigned char)c; codes[c].suffix = (unsigned char)c; }
+        std::vector<int> chain;
+        auto emit = [&](int code) {
+            chain.clear();
+            for (int c = code; c >= 0; c = codes[c].prefix) chain.push_back(c);        // stb recurses to the root first
+            for (size_t k = chain.size(); k-- > 0;)
+            {
+                if (cur_y >= max_y) return;
+                const long idx = cur_x + cur_y;
+                touched[(size_t)(idx / 4)] = 1;
+                const unsigned char* c = table[codes[chain[k]].suffix];
+                if (c[3] > 128) { out[idx] = c[2]; out[idx + 1] = c[1]; out[idx + 2] = c[0]; out[idx + 3] = c[3]; }
+                cur_x += 4;
+                if (cur_x >= max_x)
+                {
+                    cur_x = start_x;
+                    cur_y += step;
+                    while (cur_y >= max_y && parse > 0)
+                    {
+                        step = (1L << parse) * line;
+                        cur_y = start_y + (step >> 1);
+                        --parse;
+                    }
+                }
+            }
+        };
+        bool done = false;
+        while (!done)
+        {
+            if (valid_bits < codesize)
+            {
+                if (len == 0)
+                {
+                    len = r.u8();
+                    if (len == 0) break;                              // raster ends without an end code
+                }
+                --len;
+                bits |= r.u8() << valid_bits;
+                valid_bits += 8;
+                continue;
+            }
+            const int code = bits & codemask;
+            bits >>= codesize; valid_bits -= codesize;
+            if (code == clear) { codesize = lzw_cs + 1; codemask = (1 << codesize) - 1; avail = clear + 2; oldcode = -1; first = false; }
+            else if (code == clear + 1)
+            {
+                r.skip(len);
+                for (int l; (l = r.u8()) > 0;) r.skip(l);
+                done = true;
+            }
+            else if (code <= avail)
+            {
+                if (first) return false;
+                if (oldcode >= 0)
+                {
+                    Code& n = codes[avail++];
+                    if (avail > 8192) return false;
+                    n.prefix = (short)oldcode;
+                    n.first = codes[oldcode].first;
+                    n.suffix = (code == avail) ? n.first : codes[code].first;
+                }
+                else if (code == avail) return false;
+                emit(code);
+                if ((avail & codemask) == 0 && avail <= 0x0FFF) { codesize++; codemask = (1 << codesize) - 1; }
+                oldcode = code;
+            }
+            else return false;
+        }
+        if (bgindex > 0)
+            for (size_t pi = 0; pi < touched.size(); pi++)
+                if (!touched[pi])
+                {
+                    pal[bgindex][3] = 255;
+                    std::memcpy(&out[pi * 4], pal[bgindex], 4);       // B, G, R, A - stb copies the palette entry as stored
+                }
+        rgba.swap(out);
+        w = gw; h = gh;
+        return true;
+    }
+}
+
 // components of a TGA pixel / palette entry (0 = unsupported); 15/16-bit colour decodes as 5-5-5 RGB
 int tga_components(int bits, bool grey, bool* rgb16)
 {
@@ -1410,7 +1559,7 @@ void Image::Load(const std::string& filename)
     int w = 0, h = 0;
     if (!read_file(filename, file)) return;                       // missing file -> mData == 0 -> sampler returns 0
     // probe order of stbi__load_main (stb_image.h:1125-1166): PNG, BMP, ... JPEG, PNM, and TGA last (weakest signature)
-    if (!decode_png(file, w, h, rgba) && !decode_bmp(file, w, h, rgba) && !decode_jpeg(file, w, h, rgba) &&
+    if (!decode_png(file, w, h, rgba) && !decode_bmp(file, w, h, rgba) && !decode_gif(file, w, h, rgba) && !decode_jpeg(file, w, h, rgba) &&
         !decode_pnm(file, w, h, rgba) && !decode_tga(file, w, h, rgba)) return;
     if (w > 1024 || h > 1024)
     {
