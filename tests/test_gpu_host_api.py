@@ -240,3 +240,53 @@ def test_native_cpp_render_loop_matches_python_mirror(tmp_path):
     assert pt.GetSamples() == frames and out.any()
     assert np.array_equal(got, out)
     pt.close()
+
+
+def test_state_changes_between_overlapped_renders(tmp_path, oracle_mod):
+    """Renders are asynchronous and consecutive batches overlap on two internal streams; whatever the host changes in
+    between - camera, resolution, trace depth, seed, scene - the next batch must see it, and two tracers on one GPU must
+    not disturb each other.  Every stage is compared with the oracle, bit for bit."""
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
+    pts, scene, _ = S.build_config("C4", str(tmp_path / "a"), width=96, height=64, grid=16)
+    pts2, scene2, _ = S.build_config("C1", str(tmp_path / "b"), width=80, height=48)
+    pt = PathTracer(0); pt.LoadSceneFile(pts)
+    other = PathTracer(0); other.LoadSceneFile(pts2)
+
+    def check(p, sc, W, H, D, cam, first, spp, seed):
+        o = oracle_mod.Oracle(p.StagedScene())
+        ocam = oracle_mod.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+        ref, _ = o.render(ocam, W, H, D, first, spp, seed, want_rgb8=False)
+        return ref
+
+    cam = camera_from_scene(scene); cam["aperture"] = 0.0
+    pt.SetCameraAperture(0.0); pt.SetSeed(3)
+    W, H = pt.GetResolution(); D = pt.GetTraceDepth()
+    # back-to-back batches, no synchronisation in between, the other tracer rendering in the middle
+    pt.RenderFrames(3); other.RenderFrames(2); pt.RenderFrames(2); pt.RenderFrames(4)
+    assert np.array_equal(pt.ReadAccumulation(), check(pt, scene, W, H, D, cam, 0, 9, 3))
+    # new camera: the cached camera hits and the live-quadrant list must be rebuilt before the next trace kernel
+    cam["pos"] = np.array([0.3, 0.2, -3.0], np.float32)
+    pt.SetCamera(cam["pos"], cam["dir"], cam["up"]); pt.ResetImage()
+    pt.RenderFrames(2); pt.RenderFrames(3)
+    assert np.array_equal(pt.ReadAccumulation(), check(pt, scene, W, H, D, cam, 0, 5, 3))
+    # new resolution, depth and seed
+    pt.SetResolution((70, 50)); pt.SetTraceDepth(3); pt.SetSeed(8); pt.ResetImage()
+    pt.RenderFrames(4)
+    assert np.array_equal(pt.ReadAccumulation(), check(pt, scene, 70, 50, 3, cam, 0, 4, 8))
+    # thin lens: the primary-hit cache and its live masks no longer apply
+    cam["aperture"] = 0.02
+    pt.SetCameraAperture(0.02); pt.ResetImage(); pt.RenderFrames(3)
+    assert np.array_equal(pt.ReadAccumulation(), check(pt, scene, 70, 50, 3, cam, 0, 3, 8))
+    # another scene in the same tracer
+    pt.ClearScene(); pt.LoadSceneFile(pts2); pt.SetCameraAperture(0.0); pt.SetSeed(8)
+    cam2 = camera_from_scene(scene2); cam2["aperture"] = 0.0
+    W2, H2 = pt.GetResolution(); D2 = pt.GetTraceDepth()
+    pt.RenderFrames(5)
+    assert np.array_equal(pt.ReadAccumulation(), check(pt, scene2, W2, H2, D2, cam2, 0, 5, 8))
+    # the other tracer was left alone meanwhile
+    other.SetCameraAperture(0.0)          # (its two frames so far used the .pts aperture; start over with the pinhole)
+    other.ResetImage(); other.RenderFrames(3)
+    Wo, Ho = other.GetResolution()
+    assert np.array_equal(other.ReadAccumulation(), check(other, scene2, Wo, Ho, other.GetTraceDepth(), cam2, 0, 3, 0))
+    pt.close(); other.close()
