@@ -413,6 +413,46 @@ def tier_k_images(ref: Ref, tmp: str):
     g[6:8] = struct.pack("<H", 60); g[8:10] = struct.pack("<H", 41); g[11] = 7     # screen 60 x 41, background index 7
     cases.append(("gif_small_frame_bg", bytes(g)))
 
+    # ---- Radiance HDR (stbi_load reduces it to 8 bits with gamma 2.2): run-length coded scanlines, a flat file
+    # (width < 8), and the "not RLE after all" fall-back
+    def rgbe(img):
+        m = img.max(-1)
+        e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, 0).astype(np.int32)
+        sc = np.where(m > 1e-32, 256.0 / np.exp2(e.astype(np.float64)), 0.0)
+        out = np.zeros(img.shape[:2] + (4,), np.uint8)
+        out[..., :3] = np.clip(img * sc[..., None], 0, 255).astype(np.uint8)
+        out[..., 3] = np.where(m > 1e-32, e + 128, 0).astype(np.uint8)
+        return out
+
+    def hdr_file(px, rle, magic=b"#?RADIANCE"):
+        hh, ww = px.shape[:2]
+        body = b""
+        for row in px:
+            if not rle:
+                body += row.tobytes()
+                continue
+            body += bytes([2, 2, ww >> 8, ww & 255])
+            for k in range(4):
+                ch = row[:, k]
+                i = 0
+                while i < ww:
+                    run = 1
+                    while i + run < ww and run < 127 and ch[i + run] == ch[i]:
+                        run += 1
+                    if run >= 3:
+                        body += bytes([128 + run, int(ch[i])]); i += run
+                    else:
+                        n = min(ww - i, 1 + int(rng.integers(0, 9)))
+                        body += bytes([n]) + ch[i:i + n].tobytes(); i += n
+        return magic + b"\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y %d +X %d\n" % (hh, ww) + body
+    radiance = (base[:21, :29].astype(np.float64) / 255.0) ** 2.2 * 4.0
+    radiance[3:6, 4:20] = 0.0                                          # black pixels: exponent byte 0
+    radiance[8:12, :] = radiance[8:12, :1]                             # constant rows: long runs
+    e = rgbe(radiance)
+    cases.append(("hdr_rle", hdr_file(e, True)))
+    cases.append(("hdr_flat_narrow", hdr_file(e[:, :7], False, magic=b"#?RGBE")))
+    cases.append(("hdr_flat_in_rle_width", hdr_file(e, False)))
+
     # ---- BMP / TGA (the reference's texture dialog offers them, main.cpp:849): Pillow's writers plus
     # hand-packed headers for the variants Pillow cannot produce
     small = base[:11, :13]

@@ -2,7 +2,7 @@
 // on stb_image / stb_image_resize) with a small own decoder.  Off the per-sample path: images are
 // decoded once to RGBA8 and uploaded into the device texel atlas by PathTracer::BuildBVH.
 //
-// Formats: BMP and TGA (every variant stb_image 2.27 accepts), GIF (first frame), binary PNM (P5 / P6, maxval <= 255 or 16-bit), PNG incl. Adam7 interlace and colour-key tRNS (colour types 0, 2, 3, 4, 6;
+// Formats: BMP and TGA (every variant stb_image 2.27 accepts), GIF (first frame), Radiance HDR (reduced to 8 bits as stbi_load does), binary PNM (P5 / P6, maxval <= 255 or 16-bit), PNG incl. Adam7 interlace and colour-key tRNS (colour types 0, 2, 3, 4, 6;
 // bit depths 1-16) through zlib, and baseline / extended-sequential / progressive Huffman JPEG (grey, YCbCr, RGB, CMYK, YCCK).  Everything is expanded to 4 channels the way stbi_load(..., 4)
 // does (grey -> g,g,g,255; 16-bit -> high byte).  Images with a side > 1024 are reduced so the
 // longest side is 1024 (image.cpp:47-60) with stb_image_resize's default downsampling (Mitchell kernel,
@@ -1257,6 +1257,116 @@ bool decode_gif(const std::vector<unsigned char>& d, int& w, int& h, std::vector
     }
 }
 
+// ---- Radiance HDR (.hdr), reduced to 8 bits the way stbi_load does (stb_image.h:7009-7209 + stbi__hdr_to_ldr :1864-1888):
+// RGBE -> float (mantissa * 2^(e-136)), then (float)pow(v, 1/2.2f) * 255 + 0.5 truncated, alpha 255.
+bool decode_hdr(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgba)
+{
+    LeReader r(d);
+    auto token = [&]() {                                               // one header line (at most 1022 characters are kept)
+        std::string t;
+        int c = r.u8();
+        while (r.pos < r.n && c != '\n')
+        {
+            t.push_back((char)c);
+            if (t.size() == 1023) { while (r.pos < r.n && r.u8() != '\n') {} break; }
+            c = r.u8();
+        }
+        return t;
+    };
+    const std::string magic = token();
+    if (magic != "#?RADIANCE" && magic != "#?RGBE") return false;
+    bool valid = false;
+    for (;;)
+    {
+        const std::string t = token();
+        if (t.empty()) break;
+        if (t == "FORMAT=32-bit_rle_rgbe") valid = true;
+    }
+    if (!valid) return false;
+    const std::string dims = token();
+    if (dims.compare(0, 3, "-Y ") != 0) return false;
+    char* end = nullptr;
+    const int height = (int)std::strtol(dims.c_str() + 3, &end, 10);
+    while (*end == ' ') ++end;
+    if (std::strncmp(end, "+X ", 3) != 0) return false;
+    const int width = (int)std::strtol(end + 3, nullptr, 10);
+    if (width <= 0 || height <= 0 || width > (1 << 24) || height > (1 << 24) || (size_t)width * height > ((size_t)1 << 28)) return false;
+    std::vector<float> px((size_t)width * height * 3, 0.0f);
+    auto convert = [&](size_t pixel, const unsigned char* e) {
+        float* o = &px[pixel * 3];
+        if (e[3] != 0)
+        {
+            const float f1 = (float)std::ldexp(1.0f, (int)e[3] - (128 + 8));
+            o[0] = e[0] * f1; o[1] = e[1] * f1; o[2] = e[2] * f1;
+        }
+        else o[0] = o[1] = o[2] = 0.0f;
+    };
+    auto flat_from = [&](size_t first) {                               // 4 bytes per pixel, no run-length coding
+        for (size_t i = first; i < (size_t)width * height; i++)
+        {
+            unsigned char e[4];
+            for (int k = 0; k < 4; k++) e[k] = (unsigned char)r.u8();
+            convert(i, e);
+        }
+    };
+    if (width < 8 || width >= 32768) flat_from(0);
+    else
+    {
+        std::vector<unsigned char> line((size_t)width * 4);
+        for (int j = 0; j < height; j++)
+        {
+            const int c1 = r.u8(), c2 = r.u8();
+            int len = r.u8();
+            if (c1 != 2 || c2 != 2 || (len & 0x80))
+            {
+                // not run-length coded: stb takes these four bytes as pixel 0 and reads the REST of the file flat from pixel 1
+                const unsigned char e[4] = { (unsigned char)c1, (unsigned char)c2, (unsigned char)len, (unsigned char)r.u8() };
+                convert(0, e);
+                flat_from(1);
+                break;
+            }
+            len = (len << 8) | r.u8();
+            if (len != width) return false;
+            for (int k = 0; k < 4; k++)
+            {
+                int i = 0, nleft;
+                while ((nleft = width - i) > 0)
+                {
+                    int count = r.u8();
+                    if (count > 128)
+                    {
+                        const unsigned char value = (unsigned char)r.u8();
+                        count -= 128;
+                        if (count > nleft) return false;
+                        for (int z = 0; z < count; z++) line[(size_t)(i++) * 4 + k] = value;
+                    }
+                    else
+                    {
+                        if (count > nleft) return false;
+                        for (int z = 0; z < count; z++) line[(size_t)(i++) * 4 + k] = (unsigned char)r.u8();
+                    }
+                }
+            }
+            for (int i = 0; i < width; i++) convert((size_t)j * width + i, &line[(size_t)i * 4]);
+        }
+    }
+    rgba.resize((size_t)width * height * 4);
+    const float gamma_i = 1.0f / 2.2f, scale_i = 1.0f;
+    for (size_t i = 0; i < (size_t)width * height; i++)
+    {
+        for (int k = 0; k < 3; k++)
+        {
+            float z = (float)std::pow(px[i * 3 + k] * scale_i, gamma_i) * 255 + 0.5f;
+            if (z < 0) z = 0;
+            if (z > 255) z = 255;
+            rgba[i * 4 + k] = (unsigned char)(int)z;
+        }
+        rgba[i * 4 + 3] = 255;                                         // alpha 1.0f -> (int)(1 * 255 + 0.5)
+    }
+    w = width; h = height;
+    return true;
+}
+
 // components of a TGA pixel / palette entry (0 = unsupported); 15/16-bit colour decodes as 5-5-5 RGB
 int tga_components(int bits, bool grey, bool* rgb16)
 {
@@ -1560,7 +1670,7 @@ void Image::Load(const std::string& filename)
     if (!read_file(filename, file)) return;                       // missing file -> mData == 0 -> sampler returns 0
     // probe order of stbi__load_main (stb_image.h:1125-1166): PNG, BMP, ... JPEG, PNM, and TGA last (weakest signature)
     if (!decode_png(file, w, h, rgba) && !decode_bmp(file, w, h, rgba) && !decode_gif(file, w, h, rgba) && !decode_jpeg(file, w, h, rgba) &&
-        !decode_pnm(file, w, h, rgba) && !decode_tga(file, w, h, rgba)) return;
+        !decode_pnm(file, w, h, rgba) && !decode_hdr(file, w, h, rgba) && !decode_tga(file, w, h, rgba)) return;
     if (w > 1024 || h > 1024)
     {
         float scale = 1024.f / fmax(w, h);                        // image.cpp:49
