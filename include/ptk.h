@@ -30,7 +30,7 @@ extern "C" {
 #define PTK_ERR_LIMIT (-4)       /* scene exceeds a kernel limit (BVH depth, index width) */
 
 #define PTK_TILE 16              /* pixel tile edge: one 256-thread block = one 16x16 tile */
-#define PTK_MAX_BVH_DEPTH 32     /* entries of the per-lane LDS traversal stack */
+#define PTK_MAX_BVH_DEPTH 32     /* entries of the per-lane LDS traversal stack (bounds what the 4-wide tree may defer at once) */
 
 /* replaces Material (mesh.h:21-59) with texture *indices* instead of Image pointers */
 typedef struct ptk_material {
@@ -78,7 +78,7 @@ typedef struct ptk_stats {
     uint64_t samples;            /* pixel*spp processed */
     uint64_t rays;               /* closest-hit traversals (bounce + shadow rays) */
     uint64_t shadow_rays;
-    uint64_t node_visits;        /* 64-byte BVH node records fetched */
+    uint64_t node_visits;        /* 64-byte BVH node records fetched (4 child boxes each) */
     uint64_t tri_tests;          /* 48-byte triangle records fetched */
     uint64_t hits_shaded;        /* surface interactions shaded */
     uint64_t tex_fetches;        /* 4-byte texel fetches */
@@ -87,6 +87,7 @@ typedef struct ptk_stats {
     uint64_t shade_wave_execs, shade_lanes;        /* shading block executions per wave, lanes shaded */
     uint64_t gen_wave_execs, gen_lanes;            /* camera-ray block executions per wave, lanes generated */
     uint64_t tri_wave_execs, tri_lanes;            /* triangle-arm executions of the BVH walk per wave, lanes testing */
+    uint64_t max_walk_nodes;                       /* most node records a single ray fetched (tail diagnostic) */
 } ptk_stats;
 
 typedef struct ptk_ctx ptk_ctx;
@@ -147,17 +148,42 @@ int ptk_rgb8_device_ptr(ptk_ctx* ctx, void** dev_ptr, size_t* bytes);
 int ptk_bind_accum(ptk_ctx* ctx, void* dev_ptr);
 int ptk_set_stream(ptk_ctx* ctx, void* hip_stream);
 
-/* multi-GPU exchange step: sum-reduce the float accumulator to `root` over an RCCL communicator
- * (ncclComm_t passed as void*); tiles a rank does not own are zero, so the sum is a gather */
+/* ---- multi-GPU exchange step (no counterpart in the reference, which renders on one CPU: SURVEY.md 8e) -------------
+ * One process per GPU; the frame is tile-split with ptk_set_tile and each rank accumulates only its owned tiles.
+ * The exchange is a PACKED GATHER: every rank sends its owned tiles (1/world of the float accumulator) straight to the
+ * root with grouped ncclSend / ncclRecv, the root scatters them into a full image of its own (the local accumulators
+ * are untouched and keep accumulating).  Pure copies: the gathered image is bit-identical to a single-GPU render.
+ *
+ * Packed layout of rank r: its owned tiles in ascending tile order, 768 floats per tile = 16 x 16 pixels row-major from
+ * the tile's top-left corner x RGB; pixels beyond the image edge hold 0.  ptk_packed_layout writes, for every packed
+ * float, its index in the accumulator (W*H*3, rows bottom-up) or -1 for padding - host-only, needs no GPU. */
+int64_t ptk_packed_floats(int width, int height, int rank, int world);
+int ptk_packed_layout(int width, int height, int rank, int world, int64_t* src_index /* [ptk_packed_floats] */);
+
+/* the context's own RCCL communicator: rank 0 makes the 128-byte id, every rank (after receiving it by whatever
+ * rendezvous the host has - bench.py broadcasts it through torch.distributed) calls ptk_comm_init, which also sets
+ * the tile split to (rank, world) */
+int ptk_comm_unique_id(void* id_out /* 128 bytes */);
+int ptk_comm_init(ptk_ctx* ctx, const void* id /* 128 bytes */, int rank, int world);
+int ptk_comm_destroy(ptk_ctx* ctx);
+
+/* Start the exchange of the accumulator as it is after everything queued on the context's stream so far.
+ * rccl_comm: an ncclComm_t passed as void*, or NULL for the context's own (ptk_comm_init).  Asynchronous, on the
+ * context's high-priority exchange stream: pack kernel -> grouped send/recv over xGMI -> (root) unpack kernel; the
+ * render stream only waits for the pack (snapshot), so the next ptk_render overlaps the transfer. */
 int ptk_gather_accum(ptk_ctx* ctx, void* rccl_comm, int root);
+int ptk_gather_wait(ptk_ctx* ctx);                                    /* host waits for the last exchange */
+int ptk_read_gathered(ptk_ctx* ctx, float* host_out);                 /* root: W*H*3 floats, rows bottom-up; waits */
+int ptk_gathered_device_ptr(ptk_ctx* ctx, void** dev_ptr, size_t* bytes);
+/* parity probes of the pack / unpack kernels: one GPU can play every rank of a split */
+int ptk_probe_pack(ptk_ctx* ctx, int rank, int world, float* host_out /* [ptk_packed_floats] */);
+int ptk_probe_unpack(ptk_ctx* ctx, int world, const float* host_packed /* all ranks, back to back */, float* host_image);
 
 /* tuning (none changes any result): "chunk" = samples per work item (default 0 = automatic: 8, or 4 when
  * the rank's share of the frame is small); "max_batch" = queue slots a persistent wave pops at once (default 1); "persistent" = -1/0/1: waves pull
  * work items from queues until none is left (1), or one item per wave (0); default -1 = by launch size; "generations" = persistent waves retire after 1/g of their share so that other
  * streams' kernels (the exchange step) get wave slots mid-launch (default 0 = 1 on one GPU, 2 when tile-split: measured cost 0-2 %); "overlap" = 0/1 (default 1): consecutive batches trace on two alternating internal streams so that a batch's
- * tail (its few longest paths) overlaps the next batch; results and stream ordering are unchanged; "wavefront" = 0/1 (default 0): BVH scenes
- * run as alternating walk-stage / shade-stage kernels over path queues in HBM (experimental: bit-identical, slower),
- * "wavefront_paths" = paths parked at once (default 48 Mi);
+ * tail (its few longest paths) overlaps the next batch; results and stream ordering are unchanged;
  * "flat" = 0/1, scenes of <= 16 triangles skip the BVH walk and test
  * every triangle with scalar loads (default 1), "flat_shade_weight" / "flat_gen_weight" = its block-choice
  * weights in eighths (defaults 8 / 64); "pass_bytes" = HBM
@@ -176,7 +202,9 @@ int ptk_set_option(ptk_ctx* ctx, const char* name, double value);
 int ptk_last_render_ms(ptk_ctx* ctx, float* ms, int* launches);
 int ptk_last_kernel_ms(ptk_ctx* ctx, float* trace_ms, float* accumulate_ms);
 int ptk_collect_stats(ptk_ctx* ctx, uint32_t first_sample, uint32_t spp_count, uint64_t seed, ptk_stats* out);
-int ptk_bvh_info(ptk_ctx* ctx, int32_t* num_nodes, int32_t* depth, int32_t* num_leaf_tris);
+int ptk_bvh_info(ptk_ctx* ctx, int32_t* num_nodes, int32_t* depth /* wide nodes on the longest chain */, int32_t* num_leaf_tris);
+/* child boxes per node record (4), bytes per record (64), most stack entries a traversal of this tree can need */
+int ptk_bvh_layout(ptk_ctx* ctx, int32_t* node_width, int32_t* node_bytes, int32_t* stack_need);
 
 /* probes used by the parity tests (same semantics as the kernels' device functions) */
 int ptk_probe_hits(ptk_ctx* ctx, int n, const float* ro, const float* rd, int32_t* tri, float* tuv);

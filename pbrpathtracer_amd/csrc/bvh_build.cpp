@@ -1,4 +1,4 @@
-// Binned-SAH BVH2 builder (host).  See bvh_build.h.
+// Binned-SAH builder (host): BVH2 by binned SAH, collapsed to a 4-wide tree with 8-bit quantised child boxes.  See bvh_build.h.
 #include "bvh_build.h"
 
 #include <algorithm>
@@ -11,6 +11,8 @@
 
 namespace ptk {
 namespace {
+
+constexpr int32_t NODE_EXIT_CODE = INT32_MIN;     // = NODE_EXIT of ptk_device.h: a link the walk never follows
 
 constexpr int kBins = 16;
 float kTravCost = 1.0f;             // one node record = two slab tests (PTK_TRAV_COST overrides, experiments)
@@ -175,6 +177,124 @@ struct Builder {
 
 inline int32_t leaf_code(int32_t first, int32_t count) { return ~((first << 3) | (count - 1)); }
 
+// ---- BVH2 -> BVH4 collapse + 8-bit quantisation (device node layout: ptk_device.h) --------------------------------
+struct WideNode { int32_t child[4]; int n = 0; };        // tmp-node ids of the children (interior or leaf)
+
+struct Collapser {
+    const std::vector<TmpNode>& nodes;
+    std::vector<int> hb;                                  // binary height in interior nodes below and including a tmp node (leaf = 0)
+    std::vector<WideNode> wide;                           // emitted in DFS pre-order: wide[k] is device node k
+    std::vector<int32_t> wide_of;                         // tmp interior id -> device node index (only for roots of wide nodes)
+    int stack_need = 0, depth = 0;
+
+    explicit Collapser(const std::vector<TmpNode>& n) : nodes(n), hb(n.size(), 0), wide_of(n.size(), -1) {}
+    bool is_leaf(int32_t id) const { return nodes[id].left < 0; }
+
+    int height(int32_t id)
+    {
+        // iterative post-order (trees of a million triangles are deep enough to matter for the C stack only when degenerate)
+        std::vector<std::pair<int32_t, int>> st; st.push_back({ id, 0 });
+        while (!st.empty())
+        {
+            auto [x, phase] = st.back(); st.pop_back();
+            if (is_leaf(x)) { hb[x] = 0; continue; }
+            if (phase == 0) { st.push_back({ x, 1 }); st.push_back({ nodes[x].left, 0 }); st.push_back({ nodes[x].right, 0 }); }
+            else hb[x] = 1 + std::max(hb[nodes[x].left], hb[nodes[x].right]);
+        }
+        return hb[id];
+    }
+
+    // The traversal keeps at most (children - 1) deferred entries per wide node on the current root-to-leaf chain, so a
+    // subtree needs (n - 1) + max over its interior children of their need.  `budget` = stack entries left for the subtree
+    // of tmp node `id`; invariant budget >= hb[id] (a purely binary subtree needs exactly hb).  Children are absorbed
+    // largest-surface-first (the usual SAH collapse) while every member still fits the budget left after this node.
+    void collapse(int32_t root, int budget0)
+    {
+        struct Item { int32_t id; int budget; int used; int level; };
+        std::vector<Item> st; st.push_back({ root, budget0, 0, 1 });
+        while (!st.empty())
+        {
+            Item it = st.back(); st.pop_back();
+            WideNode w;
+            w.child[0] = nodes[it.id].left; w.child[1] = nodes[it.id].right; w.n = 2;
+            for (;;)
+            {
+                if (w.n == 4) break;
+                int best = -1; float best_area = -1.0f;
+                const int rem = it.budget - w.n;           // budget of the children once this node holds w.n + 1 of them
+                for (int k = 0; k < w.n; k++)
+                {
+                    const int32_t c = w.child[k];
+                    if (is_leaf(c)) continue;
+                    bool ok = hb[nodes[c].left] <= rem && hb[nodes[c].right] <= rem;
+                    for (int j = 0; j < w.n && ok; j++) if (j != k && hb[w.child[j]] > rem) ok = false;
+                    if (!ok) continue;
+                    const float a = nodes[c].box.half_area();
+                    if (a > best_area) { best_area = a; best = k; }
+                }
+                if (best < 0) break;
+                const int32_t c = w.child[best];
+                w.child[best] = nodes[c].left;
+                w.child[w.n++] = nodes[c].right;
+            }
+            wide_of[it.id] = (int32_t)wide.size();
+            wide.push_back(w);
+            const int used = it.used + (w.n - 1);
+            stack_need = std::max(stack_need, used);
+            depth = std::max(depth, it.level);
+            // DFS pre-order: push in reverse so that child 0's subtree follows its parent in memory
+            for (int k = w.n - 1; k >= 0; k--)
+                if (!is_leaf(w.child[k])) st.push_back({ w.child[k], it.budget - (w.n - 1), used, it.level + 1 });
+        }
+    }
+};
+
+// One device node: see ptk_device.h.  Boxes are quantised OUTWARD on a per-node 8-bit grid (origin + q * scale).
+void emit_node(const std::vector<TmpNode>& nodes, const Collapser& C, const WideNode& w, float* q)
+{
+    Box u; u.reset();
+    for (int k = 0; k < w.n; k++) u.grow(nodes[w.child[k]].box);
+    float origin[3], scale[3];
+    for (int a = 0; a < 3; a++)
+    {
+        origin[a] = u.mn[a];
+        double ext = (double)u.mx[a] - (double)u.mn[a];
+        float s = (float)(ext / 255.0 * (1.0 + 1e-6));
+        if (!(s > 1e-30f)) s = 1e-30f;
+        while ((double)origin[a] + 255.0 * (double)s < (double)u.mx[a]) s = std::nextafter(s, std::numeric_limits<float>::infinity());
+        scale[a] = s;
+    }
+    uint32_t lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+    int32_t link[4];
+    for (int k = 0; k < 4; k++)
+    {
+        if (k >= w.n)
+        {
+            // empty slot: an inverted box no ray can enter
+            for (int a = 0; a < 3; a++) { lo[a] |= 255u << (8 * k); hi[a] |= 0u << (8 * k); }
+            link[k] = NODE_EXIT_CODE;
+            continue;
+        }
+        const TmpNode& c = nodes[w.child[k]];
+        for (int a = 0; a < 3; a++)
+        {
+            const double o = origin[a], s = scale[a];
+            int ql = (int)std::floor(((double)c.box.mn[a] - o) / s);
+            int qh = (int)std::ceil(((double)c.box.mx[a] - o) / s);
+            ql = std::min(std::max(ql, 0), 255); qh = std::min(std::max(qh, 0), 255);
+            while (ql > 0 && o + ql * s > (double)c.box.mn[a]) ql--;
+            while (qh < 255 && o + qh * s < (double)c.box.mx[a]) qh++;
+            lo[a] |= (uint32_t)ql << (8 * k); hi[a] |= (uint32_t)qh << (8 * k);
+        }
+        link[k] = c.left < 0 ? leaf_code(c.first, c.count) : C.wide_of[w.child[k]];
+    }
+    q[0] = origin[0]; q[1] = origin[1]; q[2] = origin[2]; q[3] = scale[0];
+    q[4] = scale[1]; q[5] = scale[2];
+    std::memcpy(&q[6], &link[0], 4); std::memcpy(&q[7], &link[1], 4); std::memcpy(&q[8], &link[2], 4); std::memcpy(&q[9], &link[3], 4);
+    std::memcpy(&q[10], &lo[0], 4); std::memcpy(&q[11], &lo[1], 4); std::memcpy(&q[12], &lo[2], 4);
+    std::memcpy(&q[13], &hi[0], 4); std::memcpy(&q[14], &hi[1], 4); std::memcpy(&q[15], &hi[2], 4);
+}
+
 }  // namespace
 
 bool build_bvh(const float* verts, int32_t n, int max_depth, int leaf_max, BuiltBvh& out)
@@ -221,73 +341,32 @@ bool build_bvh(const float* verts, int32_t n, int max_depth, int leaf_max, Built
     int32_t root = B.build(0, n, 1, 0);
     if (B.failed) return false;
 
-    // flatten: interior nodes only, DFS pre-order; child boxes are stored in the parent
-    std::vector<int32_t> index(B.nodes.size(), -1);
-    std::vector<int32_t> stack;
-    int32_t num = 0;
-    const float qnan = std::numeric_limits<float>::quiet_NaN();
+    // BVH2 -> BVH4: collapse under the stack budget, then emit quantised 64-byte nodes in DFS pre-order
     auto is_leaf = [&](int32_t id) { return B.nodes[id].left < 0; };
-    std::vector<int32_t> interior;
     if (is_leaf(root))
     {
-        // a scene of <= leaf_max triangles: synthesise a root whose right child is an empty (NaN) box
+        // a scene of <= leaf_max triangles: one node whose only child is the leaf
+        Collapser C(B.nodes);
+        WideNode w; w.child[0] = root; w.n = 1;
         out.nodes.assign(16, 0.0f);
-        const TmpNode& L = B.nodes[root];
-        float* q = out.nodes.data();
-        for (int a = 0; a < 3; a++)
-        {
-            q[2 * a] = L.box.mn[a]; q[2 * a + 1] = qnan;            // (left, right) plane pairs
-            q[6 + 2 * a] = L.box.mx[a]; q[6 + 2 * a + 1] = qnan;
-        }
-        int32_t lc = leaf_code(L.first, L.count), rc = leaf_code(L.first, 1);
-        std::memcpy(&q[12], &lc, 4); std::memcpy(&q[13], &rc, 4);
-        out.num_nodes = 1; out.depth = 1;
+        emit_node(B.nodes, C, w, out.nodes.data());
+        out.num_nodes = 1; out.depth = 1; out.stack_need = 0;
     }
     else
     {
-        stack.push_back(root);
-        while (!stack.empty())
-        {
-            int32_t id = stack.back(); stack.pop_back();
-            index[id] = num++;
-            interior.push_back(id);
-            int32_t l = B.nodes[id].left, r = B.nodes[id].right;
-            if (!is_leaf(r)) stack.push_back(r);
-            if (!is_leaf(l)) stack.push_back(l);
-        }
-        out.nodes.assign((size_t)num * 16, 0.0f);
-        out.num_nodes = num;
-        for (int32_t id : interior)
-        {
-            const TmpNode& N = B.nodes[id];
-            const TmpNode& L = B.nodes[N.left];
-            const TmpNode& R = B.nodes[N.right];
-            float* q = out.nodes.data() + (size_t)index[id] * 16;
-            for (int a = 0; a < 3; a++)
-            {
-                q[2 * a] = L.box.mn[a]; q[2 * a + 1] = R.box.mn[a];   // (left, right) plane pairs
-                q[6 + 2 * a] = L.box.mx[a]; q[6 + 2 * a + 1] = R.box.mx[a];
-            }
-            int32_t lc = is_leaf(N.left) ? leaf_code(L.first, L.count) : index[N.left];
-            int32_t rc = is_leaf(N.right) ? leaf_code(R.first, R.count) : index[N.right];
-            std::memcpy(&q[12], &lc, 4); std::memcpy(&q[13], &rc, 4);
-        }
-        // depth = max number of interior nodes on a root-to-leaf chain
-        std::vector<std::pair<int32_t, int>> st; st.push_back({ root, 1 });
-        int depth = 0;
-        while (!st.empty())
-        {
-            auto [id, d] = st.back(); st.pop_back();
-            depth = std::max(depth, d);
-            int32_t l = B.nodes[id].left, r = B.nodes[id].right;
-            if (!is_leaf(l)) st.push_back({ l, d + 1 });
-            if (!is_leaf(r)) st.push_back({ r, d + 1 });
-        }
-        out.depth = depth;
+        Collapser C(B.nodes);
+        const int hroot = C.height(root);
+        if (hroot > max_depth) return false;
+        C.collapse(root, max_depth);
+        // second pass for the links: wide_of[] of every child is known only after the whole collapse
+        out.num_nodes = (int32_t)C.wide.size();
+        out.nodes.assign((size_t)out.num_nodes * 16, 0.0f);
+        for (int32_t k = 0; k < out.num_nodes; k++) emit_node(B.nodes, C, C.wide[k], out.nodes.data() + (size_t)k * 16);
+        out.depth = C.depth; out.stack_need = C.stack_need;
     }
     out.order = std::move(B.order);
     out.pad = pad;
-    return out.depth <= max_depth;
+    return out.stack_need <= max_depth;
 }
 
 }  // namespace ptk

@@ -31,7 +31,7 @@ struct ptk_ctx {
     float4 *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_mats = nullptr, *d_lights = nullptr;
     int4* d_texinfo = nullptr;
     uint32_t* d_texels = nullptr;
-    int num_nodes = 0, num_tris = 0, num_lights = 0, bvh_depth = 0, num_leaf_tris = 0;
+    int num_nodes = 0, num_tris = 0, num_lights = 0, bvh_depth = 0, bvh_stack = 0, num_leaf_tris = 0;
     bool have_scene = false;
 
     // camera (host copies, already normalised / clamped like the reference setters)
@@ -74,7 +74,7 @@ struct ptk_ctx {
     // lets one path in tens of millions live for 60+ bounces, ~0.4 ms with the rest of the chip idle) and pass k's
     // accumulate kernel.  The accumulate kernels stay on the context's stream, in order, each behind its trace kernel,
     // so everything the caller orders after ptk_render on that stream still sees the finished batch.
-    float4* d_samples = nullptr;                 // (wavefront / non-overlapped path)
+    float4* d_samples = nullptr;                 // (non-overlapped path)
     size_t samples_bytes = 0;
     float4* d_samples2[2] = { nullptr, nullptr };
     size_t samples_bytes2[2] = { 0, 0 };
@@ -86,10 +86,6 @@ struct ptk_ctx {
     unsigned pass_counter = 0;
     int opt_overlap = 1;
     int opt_chunk = 0;                           // samples per work item; 0 = automatic (8, or 4 for small shares)
-    int opt_wavefront = 0;                       // BVH scenes: 1 = walk stage / shade stage kernels over path queues instead of one kernel
-    size_t opt_wavefront_paths = (size_t)48 << 20;  // paths (128-byte records) parked at once = samples per wavefront pass
-    float4* d_paths = nullptr; unsigned* d_cont_q = nullptr; unsigned* d_shade_q = nullptr; unsigned* d_wq = nullptr;
-    size_t wf_capacity = 0;                      // entries the three buffers above hold
     int num_cus = 256;
     int opt_generations = 0;                     // 0 automatic: 1 on a single GPU, 2 when the frame is split over ranks
     int opt_persistent = -1;                     // -1 automatic (by launch size), 0 one item per wave, 1 persistent waves
@@ -97,6 +93,15 @@ struct ptk_ctx {
     int opt_tri_thr = 4;                         // triangle arm of the walk runs when queued lanes >= tri_thr/8 x walking lanes
     int opt_shade_thr = 0, opt_gen_thr = 16;     // scheduling lambdas in eighths, see trace_kernel; 0 = by tree depth
     size_t opt_pass_bytes = (size_t)4 << 30;     // sample-buffer budget per pass
+
+    // multi-GPU exchange step (ptk_gather_accum): packed gather of every rank's owned tiles to the root
+    ncclComm_t comm = nullptr;                   // the context's own communicator (ptk_comm_init), or null
+    int comm_rank = 0, comm_world = 1;
+    hipStream_t xstream = nullptr;               // high priority: its kernels and the collective take wave slots ahead of queued trace waves
+    hipEvent_t ev_rendered = nullptr, ev_packed = nullptr, ev_gathered = nullptr;
+    float* d_packed = nullptr; size_t packed_floats = 0;      // non-root: this rank's packed tiles; root: every rank's, back to back
+    float* d_gathered = nullptr; size_t gathered_floats = 0;  // root: the combined image (W*H*3, rows bottom-up)
+    bool gather_pending = false;
 
     static constexpr int kMaxTimedPasses = 64;
     hipEvent_t ev[kMaxTimedPasses][3] = {};      // per pass: before trace, after trace, after accumulate
@@ -200,7 +205,7 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     p.samples = c->d_samples;
     // shallow trees give short, uniform walks: waiting for stragglers is cheap and re-synchronises the
     // wave (lambda 25); deep trees have heavy-tailed walks: shade small batches early (lambda 5)
-    p.shade_thr = c->opt_shade_thr > 0 ? c->opt_shade_thr : (c->bvh_depth <= 8 ? 200 : 40);
+    p.shade_thr = c->opt_shade_thr > 0 ? c->opt_shade_thr : (c->bvh_depth <= 4 ? 200 : 40);
     p.gen_thr = c->opt_gen_thr;
     p.tri_thr = c->opt_tri_thr;
     p.max_batch = c->opt_max_batch;
@@ -293,9 +298,6 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
     if (chunk_opt <= 0)
         chunk_opt = (double)spp * (double)tiles * 4.0 / 8.0 >= 49152.0 ? 8 : 4;
     uint32_t max_pass = (uint32_t)std::max<size_t>(1, c->opt_pass_bytes / per_sample);
-    const bool wavefront = c->opt_wavefront != 0 && p.flat_count == 0 && c->num_tris > 0;
-    if (wavefront)      // every sample of a pass is a parked path at some point: bound the pass by the path store
-        max_pass = (uint32_t)std::max<size_t>(1, std::min<size_t>(max_pass, c->opt_wavefront_paths / ((size_t)tiles * 4 * 64)));
     if (max_pass > (uint32_t)chunk_opt) max_pass -= max_pass % (uint32_t)chunk_opt;
     uint32_t done = 0;
     while (done < spp)
@@ -304,7 +306,7 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         const int chunk = (int)std::min<uint32_t>(n, (uint32_t)chunk_opt);
         const int num_chunks = (int)((n + chunk - 1) / chunk);
         const size_t need = per_sample * (size_t)chunk * num_chunks;
-        const bool overlap = !wavefront && c->opt_overlap != 0 && c->trace_stream[0] != nullptr;
+        const bool overlap = c->opt_overlap != 0 && c->trace_stream[0] != nullptr;
         const int b = (int)(c->pass_counter & 1u);
         hipStream_t tstream = overlap ? c->trace_stream[b] : c->stream;
         if (overlap)
@@ -346,38 +348,7 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         const int pi = c->last_passes < ptk_ctx::kMaxTimedPasses ? c->last_passes : -1;
         if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][0], tstream));
         p.queues = overlap ? c->d_queues2[b] : c->d_queues;
-        if (wavefront)
-        {
-            const size_t entries = (size_t)tiles * 4 * 64 * (size_t)chunk * num_chunks;
-            if (entries > c->wf_capacity)
-            {
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                dfree(c->d_paths); dfree(c->d_cont_q); dfree(c->d_shade_q); c->wf_capacity = 0;
-                HIPCHK(c, hipMalloc(&c->d_paths, entries * 8 * sizeof(float4)));
-                // (+ the blocks of 256 entries that waves reserve and may leave partly unused: two per resident wave at most)
-                const size_t qcap = entries + (size_t)c->num_cus * 32 * 2 * 256;
-                HIPCHK(c, hipMalloc(&c->d_cont_q, qcap * sizeof(unsigned)));
-                HIPCHK(c, hipMalloc(&c->d_shade_q, qcap * sizeof(unsigned)));
-                c->wf_capacity = entries;
-            }
-            if (!c->d_wq) HIPCHK(c, hipMalloc(&c->d_wq, 128 * sizeof(unsigned)));
-            p.paths = c->d_paths; p.cont_q = c->d_cont_q; p.shade_q = c->d_shade_q; p.wq = c->d_wq;
-            // enough rounds for every path that does not survive Russian roulette beyond the depth; then look
-            int rounds = c->max_depth + 2;
-            bool first_launch = true;
-            for (int guard = 0; guard < 64; guard++)
-            {
-                launch_wavefront(p, tiles * 4, c->num_cus, rounds, first_launch, c->stream, stats);
-                HIPCHK(c, hipGetLastError());
-                first_launch = false;
-                unsigned waiting = 0;                    // paths the last walk stage queued for shading
-                HIPCHK(c, hipMemcpyAsync(&waiting, c->d_wq + 96, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                if (waiting == 0) break;
-                rounds = 4;
-            }
-        }
-        else launch_trace(p, tiles * 4, c->resident_waves, tstream, stats);
+        launch_trace(p, tiles * 4, c->resident_waves, tstream, stats);
         HIPCHK(c, hipGetLastError());
         if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][1], tstream));
         if (overlap)
@@ -441,6 +412,15 @@ int ptk_create(ptk_ctx** out, int device_ordinal)
             hipMalloc(&c->d_queues2[b], (8 * PTK_QUEUE_STRIDE + QG_WORDS) * sizeof(unsigned)) != hipSuccess)
         { ptk_destroy(c); return PTK_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming) != hipSuccess) { ptk_destroy(c); return PTK_ERR_HIP; }
+    {
+        int lo = 0, hi = 0;                      // (numerically lowest = greatest priority)
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_rendered, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming) != hipSuccess)
+        { ptk_destroy(c); return PTK_ERR_HIP; }
+    }
     *out = c;
     return PTK_OK;
 }
@@ -461,8 +441,14 @@ void ptk_destroy(ptk_ctx* c)
         dfree(c->d_samples2[b]); dfree(c->d_queues2[b]);
     }
     if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
+    if (c->xstream) { (void)hipStreamSynchronize(c->xstream); }
+    if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
+    if (c->ev_rendered) (void)hipEventDestroy(c->ev_rendered);
+    if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
+    if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
+    dfree(c->d_packed); dfree(c->d_gathered);
     dfree(c->d_exit); dfree(c->d_stats); dfree(c->d_queues); dfree(c->d_samples);
-    dfree(c->d_paths); dfree(c->d_cont_q); dfree(c->d_shade_q); dfree(c->d_wq);
     dfree(c->d_live_mask); dfree(c->d_live_list);
     for (int i = 0; i < ptk_ctx::kMaxTimedPasses; i++)
         for (int k = 0; k < 3; k++)
@@ -520,7 +506,7 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     BuiltBvh bvh;
     if (!build_bvh(s->verts, n, PTK_MAX_BVH_DEPTH, 4, bvh))
         return fail(c, PTK_ERR_LIMIT, "BVH exceeds the kernel's depth / index limits");
-    if (bvh.depth > PTK_MAX_BVH_DEPTH) return fail(c, PTK_ERR_LIMIT, "BVH deeper than the LDS traversal stack");
+    if (bvh.stack_need > PTK_MAX_BVH_DEPTH) return fail(c, PTK_ERR_LIMIT, "BVH needs more entries than the LDS traversal stack holds");
 
     // a texture with zero extent behaves like a missing image: tex2D returns 0 (image.cpp:65-66);
     // staged as a 1x1 black texel so the kernel needs no special case
@@ -630,7 +616,7 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     HIPCHK(c, up((void**)&c->d_lights, lights.data(), lights.size() * 4));
     HIPCHK(c, up((void**)&c->d_texinfo, texinfo.data(), texinfo.size() * sizeof(int4)));
     HIPCHK(c, up((void**)&c->d_texels, texels.data(), texels.size() * 4));
-    c->num_nodes = bvh.num_nodes; c->num_tris = n; c->num_lights = s->num_lights; c->bvh_depth = bvh.depth;
+    c->num_nodes = bvh.num_nodes; c->num_tris = n; c->num_lights = s->num_lights; c->bvh_depth = bvh.depth; c->bvh_stack = bvh.stack_need;
     c->scene_has_opacity = false;
     for (int32_t i = 0; i < n; i++)
         if (s->materials[s->material[i]].tex[5] >= 0) { c->scene_has_opacity = true; break; }
@@ -712,7 +698,7 @@ int ptk_render(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uint64_t s
     if (!c) return PTK_ERR_BAD_ARG;
     if (!c->have_scene) return fail(c, PTK_ERR_BAD_ARG, "ptk_upload_scene has not been called");
     if (!accum_ptr(c) || !c->d_primary) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
-    if (c->bvh_depth > PTK_MAX_BVH_DEPTH) return fail(c, PTK_ERR_LIMIT, "BVH deeper than the LDS traversal stack");
+    if (c->bvh_stack > PTK_MAX_BVH_DEPTH) return fail(c, PTK_ERR_LIMIT, "BVH needs more entries than the LDS traversal stack holds");
     HIPCHK(c, hipSetDevice(c->device));
     c->last_launches = 0;
     c->timed = false;
@@ -761,6 +747,7 @@ int ptk_collect_stats(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uin
     out->walk_wave_iters = h[7]; out->walk_lane_iters = h[8]; out->shade_wave_execs = h[9]; out->shade_lanes = h[10];
     out->gen_wave_execs = h[11]; out->gen_lanes = h[12];
     out->tri_wave_execs = h[13]; out->tri_lanes = h[14];
+    out->max_walk_nodes = h[15];
     return PTK_OK;
 }
 
@@ -849,16 +836,211 @@ int ptk_bind_accum(ptk_ctx* c, void* dev_ptr)
     return PTK_OK;
 }
 
+// ---- multi-GPU exchange step -------------------------------------------------------------------------------------
+static int64_t packed_floats_of(int width, int height, int rank, int world)
+{
+    const int64_t tiles = (int64_t)((width + PTK_TILE - 1) / PTK_TILE) * ((height + PTK_TILE - 1) / PTK_TILE);
+    const int64_t owned = tiles <= rank ? 0 : (tiles - rank + world - 1) / world;
+    return owned * PTK_TILE * PTK_TILE * 3;
+}
+
+int64_t ptk_packed_floats(int width, int height, int rank, int world)
+{
+    if (width <= 0 || height <= 0 || world < 1 || rank < 0 || rank >= world) return -1;
+    return packed_floats_of(width, height, rank, world);
+}
+
+int ptk_packed_layout(int width, int height, int rank, int world, int64_t* src_index)
+{
+    if (width <= 0 || height <= 0 || world < 1 || rank < 0 || rank >= world || !src_index) return PTK_ERR_BAD_ARG;
+    const int tiles_x = (width + PTK_TILE - 1) / PTK_TILE, num_tiles = tiles_x * ((height + PTK_TILE - 1) / PTK_TILE);
+    int64_t k = 0;
+    for (int tile = rank; tile < num_tiles; tile += world)
+    {
+        const int ty = tile / tiles_x, tx = (tile % tiles_x + tiles_x - (3 * ty) % tiles_x) % tiles_x;
+        for (int p = 0; p < PTK_TILE * PTK_TILE; p++)
+        {
+            const int px = tx * PTK_TILE + (p & 15), py = ty * PTK_TILE + (p >> 4);
+            const bool on = px < width && py < height;
+            const int64_t a = ((int64_t)(height - 1 - py) * width + px) * 3;
+            for (int ch = 0; ch < 3; ch++) src_index[k++] = on ? a + ch : -1;
+        }
+    }
+    return PTK_OK;
+}
+
+int ptk_comm_unique_id(void* id_out)
+{
+    if (!id_out) return PTK_ERR_BAD_ARG;
+    static_assert(sizeof(ncclUniqueId) == 128, "ptk.h promises 128 bytes");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return PTK_ERR_RCCL;
+    std::memcpy(id_out, &id, sizeof(id));
+    return PTK_OK;
+}
+
+int ptk_comm_init(ptk_ctx* c, const void* id_in, int rank, int world)
+{
+    if (!c || !id_in || world < 1 || world > PTK_MAX_RANKS || rank < 0 || rank >= world) return PTK_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(&id, id_in, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { c->comm = nullptr; return fail(c, PTK_ERR_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+    c->comm_rank = rank; c->comm_world = world;
+    c->rank = rank; c->world = world;            // the frame is split over the group (ptk_set_tile)
+    return PTK_OK;
+}
+
+int ptk_comm_destroy(ptk_ctx* c)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+    if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    return PTK_OK;
+}
+
+// Packed gather.  Everything is queued on the context's exchange stream behind what the render stream holds now:
+//   pack kernel (snapshot of the owned tiles; the render stream waits only for this) -> grouped ncclSend / ncclRecv
+//   (each rank's 1/world of the image goes straight to the root over its own xGMI link) -> root: unpack kernel.
+// The next ptk_render may be issued at once: its trace kernel does not touch the accumulator and overlaps the exchange.
 int ptk_gather_accum(ptk_ctx* c, void* rccl_comm, int root)
 {
-    if (!c || !rccl_comm) return PTK_ERR_BAD_ARG;
+    if (!c) return PTK_ERR_BAD_ARG;
+    ncclComm_t comm = rccl_comm ? (ncclComm_t)rccl_comm : c->comm;
+    if (!comm) return fail(c, PTK_ERR_BAD_ARG, "no communicator: pass one or call ptk_comm_init");
     if (!accum_ptr(c)) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
     HIPCHK(c, hipSetDevice(c->device));
-    size_t count = (size_t)c->width * c->height * 3;
-    // pixels of tiles a rank does not own stay exactly 0.0f, so the sum over ranks reproduces every
-    // owned value bit for bit: a gather expressed as one reduce over xGMI
-    ncclResult_t r = ncclReduce(accum_ptr(c), accum_ptr(c), count, ncclFloat, ncclSum, root, (ncclComm_t)rccl_comm, c->stream);
-    if (r != ncclSuccess) return fail(c, PTK_ERR_RCCL, std::string("ncclReduce: ") + ncclGetErrorString(r));
+    int world = 0, rank = 0;
+    if (ncclCommCount(comm, &world) != ncclSuccess || ncclCommUserRank(comm, &rank) != ncclSuccess)
+        return fail(c, PTK_ERR_RCCL, "ncclCommCount / ncclCommUserRank failed");
+    if (world != c->world || rank != c->rank) return fail(c, PTK_ERR_BAD_ARG, "communicator rank / size differ from ptk_set_tile");
+    if (root < 0 || root >= world || world > PTK_MAX_RANKS) return fail(c, PTK_ERR_BAD_ARG, "bad root");
+    const int W = c->width, H = c->height;
+    long long bases[PTK_MAX_RANKS] = { 0 };
+    size_t total = 0;
+    for (int r = 0; r < world; r++) { bases[r] = (long long)total; total += (size_t)packed_floats_of(W, H, r, world); }
+    const size_t mine = (size_t)packed_floats_of(W, H, rank, world);
+    const size_t need = rank == root ? total : mine;
+    if (need > c->packed_floats)
+    {
+        HIPCHK(c, hipStreamSynchronize(c->xstream));
+        dfree(c->d_packed); c->packed_floats = 0;
+        HIPCHK(c, hipMalloc(&c->d_packed, std::max<size_t>(need, 4) * sizeof(float)));
+        c->packed_floats = need;
+    }
+    const size_t img = (size_t)W * H * 3;
+    if (rank == root && img > c->gathered_floats)
+    {
+        HIPCHK(c, hipStreamSynchronize(c->xstream));
+        dfree(c->d_gathered); c->gathered_floats = 0;
+        HIPCHK(c, hipMalloc(&c->d_gathered, img * sizeof(float)));
+        c->gathered_floats = img;
+    }
+    HIPCHK(c, hipEventRecord(c->ev_rendered, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->xstream, c->ev_rendered, 0));
+    float* my_slot = c->d_packed + (rank == root ? bases[rank] : 0);
+    launch_pack_owned(accum_ptr(c), my_slot, W, H, rank, world, c->xstream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_packed, c->xstream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_packed, 0));      // the next accumulate_kernel may overwrite the accumulator from here on
+    if (world > 1)
+    {
+        ncclResult_t r = ncclGroupStart();
+        if (r == ncclSuccess)
+        {
+            if (rank == root)
+            {
+                for (int src = 0; src < world && r == ncclSuccess; src++)
+                {
+                    const size_t n = (size_t)packed_floats_of(W, H, src, world);
+                    if (src != root && n) r = ncclRecv(c->d_packed + bases[src], n, ncclFloat, src, comm, c->xstream);
+                }
+            }
+            else if (mine) r = ncclSend(my_slot, mine, ncclFloat, root, comm, c->xstream);
+            ncclResult_t e = ncclGroupEnd();
+            if (r == ncclSuccess) r = e;
+        }
+        if (r != ncclSuccess) return fail(c, PTK_ERR_RCCL, std::string("packed gather (ncclSend/ncclRecv): ") + ncclGetErrorString(r));
+    }
+    if (rank == root)
+    {
+        launch_unpack_all(c->d_packed, bases, c->d_gathered, W, H, world, c->xstream);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(c->ev_gathered, c->xstream));
+    c->gather_pending = true;
+    return PTK_OK;
+}
+
+int ptk_gather_wait(ptk_ctx* c)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    if (!c->gather_pending) return PTK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev_gathered));
+    c->gather_pending = false;
+    return PTK_OK;
+}
+
+int ptk_gathered_device_ptr(ptk_ctx* c, void** dev_ptr, size_t* bytes)
+{
+    if (!c || !dev_ptr) return PTK_ERR_BAD_ARG;
+    *dev_ptr = c->d_gathered;
+    if (bytes) *bytes = c->gathered_floats * sizeof(float);
+    return *dev_ptr ? PTK_OK : fail(c, PTK_ERR_BAD_ARG, "no gathered image on this rank (not the root, or ptk_gather_accum not called)");
+}
+
+int ptk_read_gathered(ptk_ctx* c, float* host_out)
+{
+    if (!c || !host_out) return PTK_ERR_BAD_ARG;
+    if (!c->d_gathered) return fail(c, PTK_ERR_BAD_ARG, "no gathered image on this rank (not the root, or ptk_gather_accum not called)");
+    int rc = ptk_gather_wait(c);
+    if (rc != PTK_OK) return rc;
+    HIPCHK(c, hipMemcpy(host_out, c->d_gathered, (size_t)c->width * c->height * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return PTK_OK;
+}
+
+// parity probes of the two exchange kernels (one GPU can play every rank of a split)
+int ptk_probe_pack(ptk_ctx* c, int rank, int world, float* host_out)
+{
+    if (!c || !host_out || world < 1 || world > PTK_MAX_RANKS || rank < 0 || rank >= world) return PTK_ERR_BAD_ARG;
+    if (!accum_ptr(c)) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)packed_floats_of(c->width, c->height, rank, world);
+    if (n == 0) return PTK_OK;
+    float* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, n * sizeof(float)));
+    launch_pack_owned(accum_ptr(c), d, c->width, c->height, rank, world, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host_out, d, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, PTK_ERR_HIP, hipGetErrorString(e));
+    return PTK_OK;
+}
+
+int ptk_probe_unpack(ptk_ctx* c, int world, const float* host_packed, float* host_image)
+{
+    if (!c || !host_packed || !host_image || world < 1 || world > PTK_MAX_RANKS) return PTK_ERR_BAD_ARG;
+    if (c->width <= 0) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    long long bases[PTK_MAX_RANKS] = { 0 };
+    size_t total = 0;
+    for (int r = 0; r < world; r++) { bases[r] = (long long)total; total += (size_t)packed_floats_of(c->width, c->height, r, world); }
+    const size_t img = (size_t)c->width * c->height * 3;
+    float *d = nullptr, *di = nullptr;
+    HIPCHK(c, hipMalloc(&d, std::max<size_t>(total, 4) * sizeof(float)));
+    if (hipMalloc(&di, img * sizeof(float)) != hipSuccess) { (void)hipFree(d); return fail(c, PTK_ERR_HIP, "hipMalloc"); }
+    hipError_t e = hipMemcpyAsync(d, host_packed, total * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(di, 0xff, img * sizeof(float), c->stream);       // NaNs: every pixel must be written
+    if (e == hipSuccess) { launch_unpack_all(d, bases, di, c->width, c->height, world, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(host_image, di, img * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d); (void)hipFree(di);
+    if (e != hipSuccess) return fail(c, PTK_ERR_HIP, hipGetErrorString(e));
     return PTK_OK;
 }
 
@@ -908,17 +1090,6 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     if (!std::strcmp(name, "overlap"))
     {
         c->opt_overlap = value != 0.0 ? 1 : 0;
-        return PTK_OK;
-    }
-    if (!std::strcmp(name, "wavefront"))
-    {
-        c->opt_wavefront = value != 0.0 ? 1 : 0;
-        return PTK_OK;
-    }
-    if (!std::strcmp(name, "wavefront_paths"))
-    {
-        if (!(value >= 65536 && value <= 1073741824.0)) return fail(c, PTK_ERR_BAD_ARG, "wavefront_paths must be in [64 Ki, 1 Gi]");
-        c->opt_wavefront_paths = (size_t)value;
         return PTK_OK;
     }
     if (!std::strcmp(name, "generations"))
@@ -977,6 +1148,15 @@ int ptk_bvh_info(ptk_ctx* c, int32_t* num_nodes, int32_t* depth, int32_t* num_le
     if (num_nodes) *num_nodes = c->num_nodes;
     if (depth) *depth = c->bvh_depth;
     if (num_leaf_tris) *num_leaf_tris = c->num_leaf_tris;
+    return PTK_OK;
+}
+
+int ptk_bvh_layout(ptk_ctx* c, int32_t* node_width, int32_t* node_bytes, int32_t* stack_need)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    if (node_width) *node_width = 4;
+    if (node_bytes) *node_bytes = NODE_F4 * 16;
+    if (stack_need) *stack_need = c->bvh_stack;
     return PTK_OK;
 }
 

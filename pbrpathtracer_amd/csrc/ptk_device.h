@@ -10,11 +10,13 @@
 
 namespace ptk {
 
-// BVH2 node, 64 B: both child boxes live in the parent so one record feeds two slab tests; the
-// planes of the left and right child are interleaved so each pair feeds one packed-f32 instruction.
-//   q0 = (lmin.x, rmin.x, lmin.y, rmin.y)   q1 = (lmin.z, rmin.z, lmax.x, rmax.x)
-//   q2 = (lmax.y, rmax.y, lmax.z, rmax.z)   q3 = (bits left, bits right, 0, 0)
-// child >= 0: interior node index; child < 0: leaf, ~child = (first_record << 3) | (count - 1)
+// BVH4 node, 64 B = one dependent fetch per FOUR child boxes (the walk is bound by the rate at which the vector memory
+// pipeline gathers records, profiles/r02/gather_ceiling.json, so bytes and records per ray are what counts).
+// Child boxes are quantised outward to 8 bits on a per-node grid: plane = origin + q * scale.
+//   q0 = (origin.xyz, scale.x)   q1 = (scale.yz, bits link0, bits link1)
+//   q2 = (bits link2, bits link3, bits lo.x, bits lo.y)   q3 = (bits lo.z, bits hi.x, bits hi.y, bits hi.z)
+// lo.a / hi.a: byte k = child k's low / high plane on axis a; an empty slot has lo = 255, hi = 0 (never entered).
+// link >= 0: interior node index; link < 0: leaf, ~link = (first_record << 3) | (count - 1)
 constexpr int NODE_F4 = 4;
 constexpr int LEAF_MAX = 8;
 constexpr int32_t NODE_EXIT = INT32_MIN;
@@ -44,6 +46,7 @@ constexpr int LIGHT_F4 = 4;
 // The accumulate kernel folds them into the float accumulator strictly in sample order, which keeps
 // the reference's `mTotalImg[px] += color` once per RenderFrame() semantics (pathtracer.cpp:798-800)
 // while the tracing itself is parallel over pixels AND samples.
+#define PTK_MAX_RANKS 64         // ranks of one exchange group (one node: 8)
 #define PTK_QUEUE_STRIDE 32     // one queue counter per 128-B line
 // words of the launch geometry that follows the 8 counters in the queue block
 enum { QG_NUM_CHUNKS = 0, QG_WORLD, QG_RANK, QG_TILES_X, QG_CHUNK, QG_SPP, QG_SLOTS, QG_LIVE_COUNT, QG_QUOTA, QG_WORDS = 16 };
@@ -53,12 +56,6 @@ struct RenderParams {
     int chunk, num_chunks;      // samples per work item, work items per 8x8 tile
     int num_items;              // owned tiles * 4 * num_chunks
     int max_batch;              // most slots a wave pops from a queue at once
-    // wavefront formulation (trace_kernel MODE 1 / 2): parked paths, their queues and the queue counters
-    float4* paths;              // 8 float4 per path, indexed by the path's sample-buffer slot
-    unsigned* cont_q;           // ids of paths that wait for their next walk
-    unsigned* shade_q;          // ids of paths that wait for shading
-    unsigned* wq;               // WQ_* counters
-    int units_enabled;          // walk stage: 1 = also starts new paths from the work items (first launch of a pass)
     int generations;            // persistent launches: waves retire after 1/generations of their share (1 = never)
     int persistent;             // 1: resident waves pull items from the queues; 0: one item per wave, named by blockIdx
     const unsigned long long* live_mask;   // per owned quadrant: its pixels that need tracing
@@ -116,10 +113,11 @@ struct ProbeParams {
 };
 
 void launch_trace(const RenderParams& p, int num_subtiles, int resident_waves, hipStream_t stream, bool stats);
-void launch_wavefront(const RenderParams& p, int num_subtiles, int cus, int rounds, bool first, hipStream_t stream, bool stats);
 void launch_pixel_rng(uint32_t seed_lo, uint32_t seed_hi, int n, uint2* out, hipStream_t stream);
 void launch_live_list(const RenderParams& p, int num_subtiles, unsigned long long* mask, unsigned* list, unsigned* count, hipStream_t stream);
 void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t stream);
+void launch_pack_owned(const float* accum, float* packed, int width, int height, int rank, int world, hipStream_t stream);
+void launch_unpack_all(const float* packed, const long long* bases, float* image, int width, int height, int world, hipStream_t stream);
 void launch_primary(const PrimaryParams& p, hipStream_t stream);
 void launch_primary_hits(const RenderParams& p, float4* out, hipStream_t stream);
 void launch_probe(const ProbeParams& p, hipStream_t stream);

@@ -21,8 +21,7 @@
 //     bounce ray) until the lane-iterations wasted by lanes parked for shading / a camera ray outweigh the
 //     lanes that block would leave idle.  Divergent blocks therefore run with full-ish EXEC masks instead of
 //     once per ray.  Scenes of <= 16 triangles skip the hierarchy (FLAT: scalar triangle loads, shadow and
-//     bounce ray in one pass).  MODE 1 / 2 compile the same body as the two stages of a wavefront formulation
-//     (evaluated, slower here - DESIGN.md 4.1).
+//     bounce ray in one pass).
 //   * Closest hit: BVH2 with both child boxes in the 64-byte parent record (left/right planes
 //     interleaved -> packed-f32 slab arithmetic), ordered descent with t-max culling, per-lane stack
 //     in LDS laid out [level][thread] (conflict-free ds_read/write_b32).  Result = min over accepted
@@ -165,7 +164,7 @@ __device__ __forceinline__ float tex2d_r(const PT& P, int tex, float uvx, float 
 
 struct Hit { int tri; float t, u, v; };
 
-struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex, walk_iters, walk_lanes, shade_execs, shade_lanes, gen_execs, gen_lanes, tri_execs, tri_lanes; };
+struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex, walk_iters, walk_lanes, shade_execs, shade_lanes, gen_execs, gen_lanes, tri_execs, tri_lanes, cur_nodes, max_nodes; };
 
 // ---- closest hit (replaces the recursive PathTracer::Hit, pathtracer.cpp:411-492) ---------------------
 // The walk is re-entrant: all of its state lives in this struct so a wave can interleave BVH steps
@@ -187,8 +186,13 @@ struct Walk {
     __device__ __forceinline__ void begin(v3 o, v3 d, int num_nodes)
     {
         ro = o; rd = d;
-        // acceleration only: 1-ulp reciprocals are fine for conservative slab tests
-        inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+        // acceleration only: 1-ulp reciprocals are fine for conservative slab tests.  Clamped to +-1e18 so that a ray
+        // parallel to an axis (a zero component: a hemisphere sample with w == 0 about an axis-aligned normal, one path in
+        // 2^24) keeps FINITE slab distances of the right sign - with +-inf the quantised form q * (scale * inv) + (origin -
+        // ro) * inv turns into NaNs on that axis, the axis stops culling and such a ray walks the whole tree (measured:
+        // 228 153 node visits for one ray of the 1 M-triangle scene, a 0.5 s tail per launch)
+        inv = V(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e18f, 1e18f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e18f, 1e18f),
+                __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e18f, 1e18f));
         node = num_nodes > 0 ? 0 : NODE_EXIT;
         sp = 0;
         tri_next = 0; tri_left = 0;
@@ -326,32 +330,51 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
         W.tri_left = stop ? 0 : W.tri_left;
         W.node = stop ? NODE_EXIT : W.node;
     }
-    if (W.node >= 0)                                      // ---- arm B: one interior node
+    if (W.node >= 0)                                      // ---- arm B: one 4-wide interior node
     {
         const float4* np = P.nodes + (size_t)W.node * NODE_F4;
-        float4 q0 = ldg4(np), q1 = ldg4(np + 1), q2 = ldg4(np + 2), q3 = ldg4(np + 3);
-        if (STATS) cnt.nodes++;
-        // (plane - origin) * inv for the left and right child at once (v_pk_add_f32 / v_pk_mul_f32)
-        f2 ox = { W.ro.x, W.ro.x }, oy = { W.ro.y, W.ro.y }, oz = { W.ro.z, W.ro.z };
-        f2 ix = { W.inv.x, W.inv.x }, iy = { W.inv.y, W.inv.y }, iz = { W.inv.z, W.inv.z };
-        f2 x0 = (f2{ q0.x, q0.y } - ox) * ix, y0 = (f2{ q0.z, q0.w } - oy) * iy, z0 = (f2{ q1.x, q1.y } - oz) * iz;
-        f2 x1 = (f2{ q1.z, q1.w } - ox) * ix, y1 = (f2{ q2.x, q2.y } - oy) * iy, z1 = (f2{ q2.z, q2.w } - oz) * iz;
-        float tnl = fmaxf(fmaxf(fminf(x0.x, x1.x), fminf(y0.x, y1.x)), fminf(z0.x, z1.x));
-        float tfl = fminf(fminf(fmaxf(x0.x, x1.x), fmaxf(y0.x, y1.x)), fmaxf(z0.x, z1.x));
-        float tnr = fmaxf(fmaxf(fminf(x0.y, x1.y), fminf(y0.y, y1.y)), fminf(z0.y, z1.y));
-        float tfr = fminf(fminf(fmaxf(x0.y, x1.y), fmaxf(y0.y, y1.y)), fmaxf(z0.y, z1.y));
-        const bool hl = (tnl <= tfl * 1.000001f) & (tfl >= 0.0f) & (tnl <= W.best.t);
-        const bool hr = (tnr <= tfr * 1.000001f) & (tfr >= 0.0f) & (tnr <= W.best.t);
-        const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-        const bool lfirst = tnl <= tnr;
-        const bool both = hl & hr;
-        if (both)
+        const float4 q0 = ldg4(np), q1 = ldg4(np + 1), q2 = ldg4(np + 2), q3 = ldg4(np + 3);
+        if (STATS) { cnt.nodes++; cnt.cur_nodes++; }
+        // child planes live on the node's 8-bit grid: plane = origin + q * scale, so along the ray
+        //   t = (plane - ro) * inv = q * (scale * inv) + (origin - ro) * inv = fma(q, A, B)
+        // (box tests are acceleration only - any conservative test gives the same closest hit - so fused
+        // multiply-adds and approximate reciprocals are fine here; the grid boxes enclose the padded boxes)
+        const float Ax = q0.w * W.inv.x, Ay = q1.x * W.inv.y, Az = q1.y * W.inv.z;
+        const float Bx = (q0.x - W.ro.x) * W.inv.x, By = (q0.y - W.ro.y) * W.inv.y, Bz = (q0.z - W.ro.z) * W.inv.z;
+        // the ray enters a slab through the low plane when it travels in +axis, through the high plane otherwise:
+        // pick the near / far plane bytes of all four children at once by the sign of the direction
+        const uint32_t mx = (uint32_t)(__float_as_int(W.inv.x) >> 31), my = (uint32_t)(__float_as_int(W.inv.y) >> 31),
+                       mz = (uint32_t)(__float_as_int(W.inv.z) >> 31);
+        const uint32_t lox = __float_as_uint(q2.z), loy = __float_as_uint(q2.w), loz = __float_as_uint(q3.x);
+        const uint32_t hix = __float_as_uint(q3.y), hiy = __float_as_uint(q3.z), hiz = __float_as_uint(q3.w);
+        const uint32_t nx = (hix & mx) | (lox & ~mx), fx = (lox & mx) | (hix & ~mx);
+        const uint32_t ny = (hiy & my) | (loy & ~my), fy = (loy & my) | (hiy & ~my);
+        const uint32_t nz = (hiz & mz) | (loz & ~mz), fz = (loz & mz) | (hiz & ~mz);
+        const int link0 = __float_as_int(q1.z), link1 = __float_as_int(q1.w), link2 = __float_as_int(q2.x), link3 = __float_as_int(q2.y);
+        const float tmax = W.best.t;
+        int key[4];
+        bool hit[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
         {
-            stack[W.sp * STRIDE] = lfirst ? right : left;       // far child waits on the stack
-            W.sp++;
+            const float tnx = __builtin_fmaf((float)((nx >> (8 * k)) & 255u), Ax, Bx), tfx = __builtin_fmaf((float)((fx >> (8 * k)) & 255u), Ax, Bx);
+            const float tny = __builtin_fmaf((float)((ny >> (8 * k)) & 255u), Ay, By), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 255u), Ay, By);
+            const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 255u), Az, Bz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 255u), Az, Bz);
+            // NaNs (0 * inf for axis-parallel rays) drop out of min3 / max3: that axis then does not constrain - conservative
+            const float tn = fmaxf(fmaxf(tnx, tny), tnz), tf = fminf(fminf(tfx, tfy), tfz);
+            hit[k] = (tn <= tf * 1.000001f) & (tf >= 0.0f) & (tn <= tmax);
+            // order key: the entry distance with the slot in its low bits (negative distances - origin inside - sort first)
+            key[k] = hit[k] ? ((__float_as_int(tn) & ~3) | k) : 0x7fffffff;
         }
-        int next = both ? (lfirst ? left : right) : (hl ? left : right);
-        if (!(hl | hr)) next = W.template pop<STRIDE>(stack);
+        const int kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+        const int near = kmin & 3;
+        int next = near == 0 ? link0 : (near == 1 ? link1 : (near == 2 ? link2 : link3));
+        // the other children that were hit wait on the stack (two hits: exactly far-after-near; more: slot order)
+        if (hit[0] & (key[0] != kmin)) { stack[W.sp * STRIDE] = link0; W.sp++; }
+        if (hit[1] & (key[1] != kmin)) { stack[W.sp * STRIDE] = link1; W.sp++; }
+        if (hit[2] & (key[2] != kmin)) { stack[W.sp * STRIDE] = link2; W.sp++; }
+        if (hit[3] & (key[3] != kmin)) { stack[W.sp * STRIDE] = link3; W.sp++; }
+        if (kmin == 0x7fffffff) next = W.template pop<STRIDE>(stack);
         W.node = next;
     }
     if (W.node < 0 && W.node != NODE_EXIT && W.tri_left == 0)   // a leaf and the triangle queue is free
@@ -389,23 +412,11 @@ enum : int { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_DONE = 3, ST_NEED = 4 };
 // lane tests every triangle, the records are fetched with SCALAR loads (one s_load per triangle per
 // wave, operands broadcast from SGPRs, no vector memory traffic and no LDS stack), and the whole walk
 // is one block of the state machine, so lanes re-synchronise by themselves.
-// MODE 0: the whole path loop in one kernel (every state of the lane state machine).
-// MODE 1 / 2: the two stages of the WAVEFRONT formulation for deep scenes - 1 = camera rays + BVH walks, 2 = surface
-// interactions - run alternately; a lane that reaches the other stage's state parks its path in HBM (128-byte
-// record, P.paths) and queues its id for the other kernel, then takes the next path from its own stage's queue, so
-// every lane of every wave does the same kind of work (the single kernel shades with 1/3 of the lanes on C4).
-enum : int { MODE_MEGA = 0, MODE_WALK = 1, MODE_SHADE = 2 };
-enum : int { WQ_CONT_HEAD = 0, WQ_CONT_TAIL = 32, WQ_SHADE_HEAD = 64, WQ_SHADE_TAIL = 96, WQ_WORDS = 128 };   // one counter per 128-B line
-enum : uint32_t { WQ_BLOCK = 256u, WQ_NONE = 0xffffffffu };    // queue entries reserved / popped per atomic; an unused entry
-
-template <bool STATS, bool FLAT, int MODE>
+template <bool STATS, bool FLAT>
 __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRACE_WAVES_BVH)) void trace_kernel(const RenderParams P)
 {
-    static_assert(MODE == MODE_MEGA || !FLAT, "the wavefront stages exist for the BVH walk only");
-    __shared__ int lds_stack[(FLAT || MODE == MODE_SHADE) ? 1 : PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
+    __shared__ int lds_stack[FLAT ? 1 : PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
     if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    if (MODE == MODE_WALK && !P.units_enabled && P.wq[WQ_CONT_TAIL] == 0u) return;          // nothing queued for this round
-    if (MODE == MODE_SHADE && P.wq[WQ_SHADE_TAIL] == 0u) return;
 
     const int tid = threadIdx.x;
     int* stack = lds_stack + tid;
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
     const v3 camRight = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
     const v3 camUp = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Rng rng;
     rng.inc = 1u; rng.state = 0; rng.key = 0;
 
@@ -576,7 +587,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
     // bounce; bounce rays end the path on a miss or queue for shading
 #define PTK_WALK_DONE()                                                                           \
     do {                                                                                          \
-        if (STATS) cnt.rays++;                                                                    \
+        if (STATS) { cnt.rays++; cnt.max_nodes = max(cnt.max_nodes, cnt.cur_nodes); cnt.cur_nodes = 0; }     \
         ray++;                                                                                    \
         const bool hit_ = W.best.tri != PTK_NOHIT;                                                \
         if (W.occl_tri >= 0)                                                                      \
@@ -592,89 +603,9 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
     } while (0)
 
     int debt_shade = 0, debt_gen = 0;      // wave-uniform: lane-iterations wasted by parked lanes
-    bool queue_dry = false;                // wavefront stages: this stage's queue has been popped past its end
-    uint32_t pop_lo = 0, pop_hi = 0;       // ... entries of it this wave has popped and not yet handed to a lane
-    uint32_t res_base = 0, res_left = 0;   // ... space this wave has reserved in the other stage's queue
     for (;;)
     {
-        if (MODE != MODE_MEGA)
-        {
-            // ---- wavefront: park the paths that reached the other stage, take queued ones of this stage ----
-            const int other = MODE == MODE_WALK ? ST_SHADE : ST_TRAV;
-            const unsigned long long m_out = __ballot(st == other);
-            if (m_out)
-            {
-                // queue space is reserved WQ_BLOCK entries at a time (one atomic per block, not per push: a single
-                // counter takes ~90 atomics/us); what a wave leaves unused of its block holds WQ_NONE
-                unsigned* outq = MODE == MODE_WALK ? P.shade_q : P.cont_q;
-                const uint32_t n_out = (uint32_t)__popcll(m_out);
-                if (res_left < n_out)
-                {
-                    for (uint32_t i = (uint32_t)lane; i < res_left; i += 64u) outq[res_base + i] = WQ_NONE;
-                    uint32_t nb = 0;
-                    if (lane == 0) nb = atomicAdd(&P.wq[MODE == MODE_WALK ? WQ_SHADE_TAIL : WQ_CONT_TAIL], (uint32_t)WQ_BLOCK);
-                    res_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-                    res_left = WQ_BLOCK;
-                }
-                const uint32_t base = res_base;
-                res_base += n_out; res_left -= n_out;
-                if (st == other)
-                {
-                    float4* rec = P.paths + (size_t)out_idx * 8;
-                    rec[0] = make_float4(W.ro.x, W.ro.y, W.ro.z, W.rd.x);
-                    rec[1] = make_float4(W.rd.y, W.rd.z, W.best.t, W.best.u);
-                    rec[2] = make_float4(W.best.v, __int_as_float(W.best.tri), L.x, L.y);
-                    rec[3] = make_float4(L.z, T.x, T.y, T.z);
-                    rec[4] = make_float4(Tdi.x, Tdi.y, Tdi.z, nextDir.x);
-                    rec[5] = make_float4(nextDir.y, nextDir.z, W.occl_limit, __int_as_float(W.occl_tri));
-                    rec[6] = make_float4(__uint_as_float(rng.state), __uint_as_float(rng.inc), __uint_as_float(rng.key), __uint_as_float(out_idx));
-                    rec[7] = make_float4(__int_as_float(depth), __int_as_float(iter), __int_as_float(inside ? 1 : 0), __uint_as_float(ray));
-                    outq[base + (uint32_t)__popcll(m_out & ((1ull << lane) - 1ull))] = out_idx;
-                    st = ST_NEED;
-                }
-            }
-            unsigned long long m_need = __ballot(st == ST_NEED);
-            while (m_need && !(queue_dry && pop_lo >= pop_hi))
-            {
-                if (pop_lo >= pop_hi)
-                {
-                    uint32_t nb = 0;
-                    if (lane == 0) nb = atomicAdd(&P.wq[MODE == MODE_WALK ? WQ_CONT_HEAD : WQ_SHADE_HEAD], (uint32_t)WQ_BLOCK);
-                    nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-                    const uint32_t tail = P.wq[MODE == MODE_WALK ? WQ_CONT_TAIL : WQ_SHADE_TAIL];   // fixed while this kernel runs
-                    pop_lo = min(nb, tail); pop_hi = min(nb + (uint32_t)WQ_BLOCK, tail);
-                    queue_dry = nb + (uint32_t)WQ_BLOCK >= tail;
-                    if (pop_lo >= pop_hi) break;
-                }
-                const uint32_t mine = pop_lo + (uint32_t)__popcll(m_need & ((1ull << lane) - 1ull));
-                const uint32_t take = min((uint32_t)__popcll(m_need), pop_hi - pop_lo);
-                uint32_t id = WQ_NONE;
-                if (st == ST_NEED && mine < pop_hi) id = (MODE == MODE_WALK ? P.cont_q : P.shade_q)[mine];
-                pop_lo += take;
-                if (id != WQ_NONE)
-                {
-                    out_idx = id;
-                    const float4* rec = P.paths + (size_t)out_idx * 8;
-                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6], r7 = rec[7];
-                    W.begin(V(r0.x, r0.y, r0.z), V(r0.w, r1.x, r1.y), P.num_nodes);     // (a fresh walk for MODE_WALK)
-                    if (MODE == MODE_SHADE) { W.best.t = r1.z; W.best.u = r1.w; W.best.v = r2.x; W.best.tri = __float_as_int(r2.y); }
-                    L = V(r2.z, r2.w, r3.x); T = V(r3.y, r3.z, r3.w);
-                    Tdi = V(r4.x, r4.y, r4.z); nextDir = V(r4.w, r5.x, r5.y);
-                    W.occl_limit = r5.z; W.occl_tri = __float_as_int(r5.w);
-                    rng.state = __float_as_uint(r6.x); rng.inc = __float_as_uint(r6.y); rng.key = __float_as_uint(r6.z);
-                    depth = __float_as_int(r7.x); iter = __float_as_int(r7.y); inside = __float_as_int(r7.z) != 0; ray = __float_as_uint(r7.w);
-                    st = MODE == MODE_WALK ? ST_TRAV : ST_SHADE;
-                }
-                m_need = __ballot(st == ST_NEED);
-            }
-            if (MODE == MODE_SHADE || !P.units_enabled)
-            {
-                // no camera rays in this launch: lanes the queue could not feed are finished
-                if (st == ST_NEED && queue_dry && pop_lo >= pop_hi) st = ST_DONE;
-            }
-        }
         // deal the next work units to the lanes that need one (wave-uniform code)
-        if (MODE == MODE_MEGA || (MODE == MODE_WALK && P.units_enabled))
         {
             unsigned long long m_need = __ballot(st == ST_NEED);
             while (m_need)
@@ -760,7 +691,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
             run_shade = n_shade > 0 && (sc_shade >= sc_gen || n_gen == 0);
             run_gen = !run_shade;
         }
-        else if (MODE != MODE_SHADE && n_trav > 0)
+        else if (n_trav > 0)
         {
             // ---- BVH walk ----
             do
@@ -791,16 +722,14 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 const int ng = __popcll(__ballot(st == ST_GEN)) + __popcll(m_nd);
                 const int nl = nt + ns + ng;
                 debt_shade += ns; debt_gen += ng;
-                if (ns > 0 && debt_shade * 8 >= (MODE == MODE_WALK ? P.gen_thr : P.shade_thr) * (nl - ns)) { run_shade = true; break; }
+                if (ns > 0 && debt_shade * 8 >= P.shade_thr * (nl - ns)) { run_shade = true; break; }
                 if (ng > 0 && debt_gen * 8 >= P.gen_thr * (nl - ng)) { run_gen = m_nd == 0ull; break; }   // NEED lanes: re-vote via the top of the loop
                 if (nt == 0) break;
             } while (true);
             if (!run_shade && !run_gen) continue;        // the walk ran dry: re-vote
         }
         if (run_shade) debt_shade = 0; else debt_gen = 0;
-        if (MODE == MODE_WALK && run_shade) continue;       // hits are parked for the shade stage at the top of the loop
-        if (MODE == MODE_SHADE && !run_shade) continue;
-        if (MODE != MODE_WALK && run_shade)
+        if (run_shade)
         {
             if (STATS) { const uint32_t nsx = (uint32_t)__popcll(__ballot(st == ST_SHADE)); if (lane == 0) { cnt.shade_execs++; cnt.shade_lanes += nsx; } }
             if (st == ST_SHADE)
@@ -1007,7 +936,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 if (ended) PTK_FINISH_PATH();
             }
         }
-        else if (MODE != MODE_SHADE)
+        else
         {
             if (STATS) { const uint32_t ngx = (uint32_t)__popcll(__ballot(st == ST_GEN)); if (lane == 0) { cnt.gen_execs++; cnt.gen_lanes += ngx; } }
             if (st == ST_GEN)
@@ -1056,9 +985,6 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
     }
 #undef PTK_WALK_DONE
 #undef PTK_FINISH_PATH
-    if (MODE != MODE_MEGA)      // what is left of the last reserved queue block stays empty
-        for (uint32_t i = (uint32_t)lane; i < res_left; i += 64u) (MODE == MODE_WALK ? P.shade_q : P.cont_q)[res_base + i] = WQ_NONE;
-
     if (STATS)
     {
         atomicAdd(&P.stats[1], (unsigned long long)cnt.rays);
@@ -1067,6 +993,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
         atomicAdd(&P.stats[4], (unsigned long long)cnt.tris);
         atomicAdd(&P.stats[5], (unsigned long long)cnt.shaded);
         atomicAdd(&P.stats[6], (unsigned long long)cnt.tex);
+        atomicMax(&P.stats[15], (unsigned long long)cnt.max_nodes);
         if (lane == 0)
         {
             atomicAdd(&P.stats[7], (unsigned long long)cnt.walk_iters);
@@ -1162,7 +1089,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void primary_hits_kernel(const RenderPar
     const int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (i >= P.width * P.height) return;
     Rng rng; rng.inc = 1u; rng.state = 0u; rng.key = 0u;            // no opacity draws can occur here
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     float4 d = P.primary[i];
     const v3 camPos0 = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
     v3 focalPoint = add(camPos0, muls(V(d.x, d.y, d.z), P.focal_dist));
@@ -1181,7 +1108,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_hits_kernel(const ProbeParams
     int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (i >= P.n) return;
     Rng rng; rng.inc = (hash32(0u ^ 0x9E3779B9u) << 1) | 1u; rng.state = hash32(0u); rng.key = rng.state;
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     v3 ro = V(P.ro[i * 3], P.ro[i * 3 + 1], P.ro[i * 3 + 2]);
     v3 rd = V(P.rd[i * 3], P.rd[i * 3 + 1], P.rd[i * 3 + 2]);
     Walk W;
@@ -1293,66 +1220,62 @@ void launch_trace(const RenderParams& p0, int num_subtiles, int resident_waves, 
     geo.w[QG_QUOTA] = generations > 1 ? blocks : 0;
     hipLaunchKernelGGL(queue_init_kernel, dim3(1), dim3(64), 0, stream, p.queues, geo, p.live_count);
     const bool flat = p.flat_count > 0;
-    if (stats && flat) hipLaunchKernelGGL((trace_kernel<true, true, MODE_MEGA>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    else if (stats) hipLaunchKernelGGL((trace_kernel<true, false, MODE_MEGA>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    else if (flat) hipLaunchKernelGGL((trace_kernel<false, true, MODE_MEGA>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    else hipLaunchKernelGGL((trace_kernel<false, false, MODE_MEGA>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    if (stats && flat) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else if (stats) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else if (flat) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
 }
 
-// ---- wavefront formulation (BVH scenes): walk stage and shade stage alternate over path queues in HBM ----
-__global__ void wavefront_flip_kernel(unsigned* wq, int next_stage)
-{
-    // before the walk stage (1): it consumes the continuation queue from its start and refills the shade queue;
-    // before the shade stage (2): the other way round; 0: a new pass, everything empty
-    if (threadIdx.x != 0) return;
-    if (next_stage == 0) { wq[WQ_CONT_HEAD] = wq[WQ_CONT_TAIL] = wq[WQ_SHADE_HEAD] = wq[WQ_SHADE_TAIL] = 0u; }
-    else if (next_stage == MODE_WALK) { wq[WQ_CONT_HEAD] = 0u; wq[WQ_SHADE_HEAD] = wq[WQ_SHADE_TAIL] = 0u; }
-    else { wq[WQ_SHADE_HEAD] = 0u; wq[WQ_CONT_HEAD] = wq[WQ_CONT_TAIL] = 0u; }
-}
+// ---- multi-GPU exchange step: packed form of the float accumulator ---------------------------------
+// Packed layout of rank r of `world` (include/ptk.h ptk_packed_layout): its owned tiles in ascending tile order, 768
+// floats each = the tile's 16 x 16 pixels row-major from the tile's top-left, RGB; pixels off the image hold 0.
+// pack: accumulator -> packed (one workgroup per owned tile, 768 B contiguous per wave-store);
+// unpack: the packed buffers of ALL ranks (rank r's starts at float offset base[r]) -> full image, one workgroup per tile.
+struct ExchangeBases { long long base[PTK_MAX_RANKS]; };
 
-int wavefront_resident_waves(bool stats, int stage, int cus)
+__global__ __launch_bounds__(PTK_BLOCK) void pack_owned_kernel(const float* __restrict__ accum, float* __restrict__ packed, int width, int height,
+                                                               int tiles_x, int num_tiles, int rank, int world)
 {
-    int per_cu = 0;
-    hipError_t e;
-    if (stage == MODE_WALK)
-        e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<true, false, MODE_WALK>, PTK_TRACE_BLOCK, 0)
-                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, false, MODE_WALK>, PTK_TRACE_BLOCK, 0);
-    else
-        e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<true, false, MODE_SHADE>, PTK_TRACE_BLOCK, 0)
-                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_kernel<false, false, MODE_SHADE>, PTK_TRACE_BLOCK, 0);
-    if (e != hipSuccess || per_cu <= 0) per_cu = 16;
-    return per_cu * cus;
-}
-
-// One pass of the wavefront formulation: camera rays + first walks, then `rounds` x (shade stage, walk stage).  A stage
-// whose queue is empty returns at once, so a generous `rounds` costs launches, not work; the caller checks the queues
-// afterwards (paths that survive Russian roulette for longer are possible, if rare) and runs more rounds if needed.
-void launch_wavefront(const RenderParams& p0, int num_subtiles, int cus, int rounds, bool first, hipStream_t stream, bool stats)
-{
-    if (num_subtiles <= 0) return;
-    RenderParams p = p0;
-    const int walk_blocks = wavefront_resident_waves(stats, MODE_WALK, cus), shade_blocks = wavefront_resident_waves(stats, MODE_SHADE, cus);
-    if (first)
+    const int owned = blockIdx.x, tile = owned * world + rank;
+    if (tile >= num_tiles) return;
+    const int ty = tile / tiles_x, tx = (tile % tiles_x + tiles_x - (3 * ty) % tiles_x) % tiles_x;
+    const int p = threadIdx.x, px = tx * PTK_TILE + (p & 15), py = ty * PTK_TILE + (p >> 4);
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    if (px < width && py < height)
     {
-        QueueGeometry geo = {};
-        geo.w[QG_NUM_CHUNKS] = p.num_chunks; geo.w[QG_WORLD] = p.world; geo.w[QG_RANK] = p.rank;
-        geo.w[QG_TILES_X] = p.tiles_x; geo.w[QG_CHUNK] = p.chunk; geo.w[QG_SPP] = (int)p.spp;
-        hipLaunchKernelGGL(queue_init_kernel, dim3(1), dim3(64), 0, stream, p.queues, geo, p.live_count);
-        hipLaunchKernelGGL(wavefront_flip_kernel, dim3(1), dim3(64), 0, stream, p.wq, 0);
-        p.persistent = 1; p.units_enabled = 1;
-        if (stats) hipLaunchKernelGGL((trace_kernel<true, false, MODE_WALK>), dim3(walk_blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-        else hipLaunchKernelGGL((trace_kernel<false, false, MODE_WALK>), dim3(walk_blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+        const size_t a = ((size_t)(height - 1 - py) * width + px) * 3;
+        r = accum[a]; g = accum[a + 1]; b = accum[a + 2];
     }
-    p.persistent = 1; p.units_enabled = 0;
-    for (int r = 0; r < rounds; r++)
-    {
-        hipLaunchKernelGGL(wavefront_flip_kernel, dim3(1), dim3(64), 0, stream, p.wq, (int)MODE_SHADE);
-        if (stats) hipLaunchKernelGGL((trace_kernel<true, false, MODE_SHADE>), dim3(shade_blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-        else hipLaunchKernelGGL((trace_kernel<false, false, MODE_SHADE>), dim3(shade_blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-        hipLaunchKernelGGL(wavefront_flip_kernel, dim3(1), dim3(64), 0, stream, p.wq, (int)MODE_WALK);
-        if (stats) hipLaunchKernelGGL((trace_kernel<true, false, MODE_WALK>), dim3(walk_blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-        else hipLaunchKernelGGL((trace_kernel<false, false, MODE_WALK>), dim3(walk_blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    }
+    float* o = packed + (size_t)owned * (PTK_BLOCK * 3) + p * 3;
+    o[0] = r; o[1] = g; o[2] = b;
+}
+
+__global__ __launch_bounds__(PTK_BLOCK) void unpack_all_kernel(const float* __restrict__ packed, const ExchangeBases bases, float* __restrict__ image,
+                                                               int width, int height, int tiles_x, int num_tiles, int world)
+{
+    const int tile = blockIdx.x;
+    if (tile >= num_tiles) return;
+    const int rank = tile % world, owned = tile / world;
+    const int ty = tile / tiles_x, tx = (tile % tiles_x + tiles_x - (3 * ty) % tiles_x) % tiles_x;
+    const int p = threadIdx.x, px = tx * PTK_TILE + (p & 15), py = ty * PTK_TILE + (p >> 4);
+    if (px >= width || py >= height) return;
+    const float* in = packed + bases.base[rank] + (size_t)owned * (PTK_BLOCK * 3) + p * 3;
+    const size_t a = ((size_t)(height - 1 - py) * width + px) * 3;
+    image[a] = in[0]; image[a + 1] = in[1]; image[a + 2] = in[2];
+}
+
+void launch_pack_owned(const float* accum, float* packed, int width, int height, int rank, int world, hipStream_t stream)
+{
+    const int tiles_x = (width + PTK_TILE - 1) / PTK_TILE, num_tiles = tiles_x * ((height + PTK_TILE - 1) / PTK_TILE);
+    const int owned = num_tiles <= rank ? 0 : (num_tiles - rank + world - 1) / world;
+    if (owned > 0) hipLaunchKernelGGL(pack_owned_kernel, dim3(owned), dim3(PTK_BLOCK), 0, stream, accum, packed, width, height, tiles_x, num_tiles, rank, world);
+}
+void launch_unpack_all(const float* packed, const long long* bases, float* image, int width, int height, int world, hipStream_t stream)
+{
+    const int tiles_x = (width + PTK_TILE - 1) / PTK_TILE, num_tiles = tiles_x * ((height + PTK_TILE - 1) / PTK_TILE);
+    ExchangeBases b = {};
+    for (int r = 0; r < world && r < PTK_MAX_RANKS; r++) b.base[r] = bases[r];
+    hipLaunchKernelGGL(unpack_all_kernel, dim3(num_tiles), dim3(PTK_BLOCK), 0, stream, packed, b, image, width, height, tiles_x, num_tiles, world);
 }
 
 void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t stream)

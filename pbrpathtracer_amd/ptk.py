@@ -43,7 +43,7 @@ class Stats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
                 ("samples", "rays", "shadow_rays", "node_visits", "tri_tests", "hits_shaded", "tex_fetches",
                  "walk_wave_iters", "walk_lane_iters", "shade_wave_execs", "shade_lanes", "gen_wave_execs", "gen_lanes",
-                 "tri_wave_execs", "tri_lanes")]
+                 "tri_wave_execs", "tri_lanes", "max_walk_nodes")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -62,7 +62,9 @@ SYMBOLS = [
     "ptk_request_exit", "ptk_synchronize", "ptk_last_error", "ptk_accum_device_ptr", "ptk_rgb8_device_ptr",
     "ptk_bind_accum", "ptk_set_stream", "ptk_gather_accum", "ptk_set_option", "ptk_last_render_ms",
     "ptk_last_kernel_ms", "ptk_collect_stats",
-    "ptk_bvh_info", "ptk_probe_hits", "ptk_probe_primary_dirs", "ptk_host_alloc", "ptk_host_free",
+    "ptk_bvh_info", "ptk_bvh_layout", "ptk_probe_hits", "ptk_probe_primary_dirs", "ptk_host_alloc", "ptk_host_free",
+    "ptk_packed_floats", "ptk_packed_layout", "ptk_comm_unique_id", "ptk_comm_init", "ptk_comm_destroy",
+    "ptk_gather_wait", "ptk_read_gathered", "ptk_gathered_device_ptr", "ptk_probe_pack", "ptk_probe_unpack",
 ]
 
 
@@ -99,11 +101,22 @@ def load() -> C.CDLL:
     L.ptk_bind_accum.argtypes = [vp, vp]
     L.ptk_set_stream.argtypes = [vp, vp]
     L.ptk_gather_accum.argtypes = [vp, vp, i32]
+    L.ptk_packed_floats.argtypes = [i32, i32, i32, i32]; L.ptk_packed_floats.restype = C.c_int64
+    L.ptk_packed_layout.argtypes = [i32, i32, i32, i32, vp]
+    L.ptk_comm_unique_id.argtypes = [vp]
+    L.ptk_comm_init.argtypes = [vp, vp, i32, i32]
+    L.ptk_comm_destroy.argtypes = [vp]
+    L.ptk_gather_wait.argtypes = [vp]
+    L.ptk_read_gathered.argtypes = [vp, vp]
+    L.ptk_gathered_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ptk_probe_pack.argtypes = [vp, i32, i32, vp]
+    L.ptk_probe_unpack.argtypes = [vp, i32, vp, vp]
     L.ptk_last_render_ms.argtypes = [vp, fp, C.POINTER(i32)]
     L.ptk_last_kernel_ms.argtypes = [vp, fp, fp]
     L.ptk_set_option.argtypes = [vp, C.c_char_p, C.c_double]
     L.ptk_collect_stats.argtypes = [vp, u32, u32, u64, C.POINTER(Stats)]
     L.ptk_bvh_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.ptk_bvh_layout.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ptk_probe_hits.argtypes = [vp, i32, vp, vp, vp, vp]
     L.ptk_probe_primary_dirs.argtypes = [vp, vp]
     _lib = L
@@ -239,6 +252,14 @@ class Context:
         self._chk(self.L.ptk_bvh_info(self.h, C.byref(n), C.byref(d), C.byref(t)), "ptk_bvh_info")
         return n.value, d.value, t.value
 
+    def bvh_layout(self):
+        w = C.c_int32(); b = C.c_int32(); s = C.c_int32()
+        self._chk(self.L.ptk_bvh_layout(self.h, C.byref(w), C.byref(b), C.byref(s)), "ptk_bvh_layout")
+        return w.value, b.value, s.value
+
+    def node_width(self) -> int:
+        return self.bvh_layout()[0]
+
     def accum_device_ptr(self):
         p = C.c_void_p(); b = C.c_size_t()
         self._chk(self.L.ptk_accum_device_ptr(self.h, C.byref(p), C.byref(b)), "ptk_accum_device_ptr")
@@ -249,6 +270,36 @@ class Context:
 
     def set_stream(self, stream_handle: int):
         self._chk(self.L.ptk_set_stream(self.h, stream_handle), "ptk_set_stream")
+
+    # ---- multi-GPU exchange step -------------------------------------------------------------
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        self._chk(self.L.ptk_comm_init(self.h, C.c_char_p(unique_id), rank, world), "ptk_comm_init")
+
+    def comm_destroy(self):
+        self._chk(self.L.ptk_comm_destroy(self.h), "ptk_comm_destroy")
+
+    def gather_accum(self, root: int = 0, comm=None):
+        self._chk(self.L.ptk_gather_accum(self.h, comm, root), "ptk_gather_accum")
+
+    def gather_wait(self):
+        self._chk(self.L.ptk_gather_wait(self.h), "ptk_gather_wait")
+
+    def read_gathered(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._chk(self.L.ptk_read_gathered(self.h, out.ctypes.data), "ptk_read_gathered")
+        return out
+
+    def probe_pack(self, rank: int, world: int) -> np.ndarray:
+        out = np.zeros(packed_floats(self.width, self.height, rank, world), np.float32)
+        self._chk(self.L.ptk_probe_pack(self.h, rank, world, out.ctypes.data), "ptk_probe_pack")
+        return out
+
+    def probe_unpack(self, world: int, packed_all: np.ndarray) -> np.ndarray:
+        p = np.ascontiguousarray(packed_all, np.float32)
+        out = np.empty((self.height, self.width, 3), np.float32)
+        self._chk(self.L.ptk_probe_unpack(self.h, world, p.ctypes.data, out.ctypes.data), "ptk_probe_unpack")
+        return out
 
     # ---- probes ----------------------------------------------------------------------------
     def probe_hits(self, ro: np.ndarray, rd: np.ndarray):
@@ -262,3 +313,26 @@ class Context:
         out = np.empty((self.height, self.width, 3), np.float32)
         self._chk(self.L.ptk_probe_primary_dirs(self.h, out.ctypes.data), "ptk_probe_primary_dirs")
         return out
+
+
+# ---- packed exchange layout (host-only functions of the library: no GPU needed) ---------------------------------
+def packed_floats(width: int, height: int, rank: int, world: int) -> int:
+    n = load().ptk_packed_floats(width, height, rank, world)
+    if n < 0:
+        raise PtkError("ptk_packed_floats: bad arguments")
+    return int(n)
+
+
+def packed_layout(width: int, height: int, rank: int, world: int) -> np.ndarray:
+    """For every float of rank `rank`'s packed buffer: its index in the accumulator (W*H*3, rows bottom-up), -1 = padding."""
+    idx = np.empty(packed_floats(width, height, rank, world), np.int64)
+    if load().ptk_packed_layout(width, height, rank, world, idx.ctypes.data) != PTK_OK:
+        raise PtkError("ptk_packed_layout: bad arguments")
+    return idx
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    if load().ptk_comm_unique_id(buf) != PTK_OK:
+        raise PtkError("ptk_comm_unique_id (ncclGetUniqueId) failed")
+    return buf.raw

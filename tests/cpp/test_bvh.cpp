@@ -1,6 +1,6 @@
 // CPU test of the host BVH builder (pbrpathtracer_amd/csrc/bvh_build.cpp): structural validity of the
-// device layout (indices in range, every triangle in exactly one leaf, child boxes enclose their
-// triangles with the conservative padding, depth bound honoured).  Built and run by tests/test_host_cpu.py.
+// device layout (4-wide nodes with 8-bit quantised child boxes: indices in range, every triangle in exactly one leaf,
+// the quantised child boxes enclose their triangles strictly, nested boxes nest, stack bound honoured and reported).  Built and run by tests/test_host_cpu.py.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -13,30 +13,68 @@
 
 using namespace ptk;
 
-static int check(const std::vector<float>& verts, int n, int max_depth, int leaf_max, const char* name)
+// device node (ptk_device.h): 16 dwords = origin.xyz, scale.xyz, 4 links, lo.x lo.y lo.z hi.x hi.y hi.z (one byte per child)
+static int check(const std::vector<float>& verts, int n, int max_stack, int leaf_max, const char* name)
 {
     BuiltBvh b;
-    if (!build_bvh(verts.data(), n, max_depth, leaf_max, b)) { std::printf("FAIL %s: build_bvh returned false\n", name); return 1; }
+    if (!build_bvh(verts.data(), n, max_stack, leaf_max, b)) { std::printf("FAIL %s: build_bvh returned false\n", name); return 1; }
     if (n == 0) { if (b.num_nodes != 0) { std::printf("FAIL %s: nodes for empty scene\n", name); return 1; } return 0; }
     if ((int)b.order.size() != n) { std::printf("FAIL %s: order size\n", name); return 1; }
-    std::vector<int> seen(n, 0);
-    int maxdepth = 0; long errors = 0;
-    std::function<void(int, int)> walk = [&](int node, int depth) {
+    std::vector<int> seen(n, 0), visited(b.num_nodes, 0);
+    int maxdepth = 0, maxneed = 0; long errors = 0; long children = 0;
+    // (node, wide depth, entries deferred above it)
+    std::function<void(int, int, int)> walk = [&](int node, int depth, int used) {
         if (node < 0 || node >= b.num_nodes) { errors++; return; }
+        if (visited[node]++) { errors++; return; }
         if (depth > maxdepth) maxdepth = depth;
-        if (depth > max_depth + 1) { errors++; return; }
         const float* q = b.nodes.data() + (size_t)node * 16;
-        int32_t child[2]; std::memcpy(child, q + 12, 8);
-        // planes are stored as (left, right) pairs: min x, y, z then max x, y, z
-        const float box[2][6] = { { q[0], q[2], q[4], q[6], q[8], q[10] }, { q[1], q[3], q[5], q[7], q[9], q[11] } };
-        for (int c = 0; c < 2; c++)
+        int32_t link[4]; uint32_t lo[3], hi[3];
+        std::memcpy(link, q + 6, 16); std::memcpy(lo, q + 10, 12); std::memcpy(hi, q + 13, 12);
+        int nc = 0;
+        for (int c = 0; c < 4; c++) if (((lo[0] >> (8 * c)) & 255u) <= ((hi[0] >> (8 * c)) & 255u)) nc++;
+        if (nc == 0) { errors++; return; }
+        children += nc;
+        const int used_here = used + nc - 1;
+        if (used_here > maxneed) maxneed = used_here;
+        for (int c = 0; c < 4; c++)
         {
-            if (std::isnan(box[c][0])) continue;      // empty child
-            if (child[c] >= 0) { if (child[c] <= node) errors++; walk(child[c], depth + 1); }
-            else
+            double box[6];
+            bool empty = false;
+            for (int a = 0; a < 3; a++)
             {
-                int code = ~child[c]; int first = code >> 3, count = (code & 7) + 1;
-                if (first < 0 || first + count > n || count > leaf_max) { errors++; continue; }
+                const unsigned ql = (lo[a] >> (8 * c)) & 255u, qh = (hi[a] >> (8 * c)) & 255u;
+                if (ql > qh) empty = true;
+                box[a] = (double)q[a] + ql * (double)q[3 + a]; box[3 + a] = (double)q[a] + qh * (double)q[3 + a];
+            }
+            if (empty)
+            {
+                // an empty slot is empty on every axis and never followed
+                for (int a = 0; a < 3; a++) if (((lo[a] >> (8 * c)) & 255u) <= ((hi[a] >> (8 * c)) & 255u)) errors++;
+                continue;
+            }
+            // every triangle below must lie strictly inside the quantised box (it encloses the padded boxes)
+            std::function<void(int32_t)> inside = [&](int32_t l) {
+                if (l >= 0)
+                {
+                    const float* cq = b.nodes.data() + (size_t)l * 16;
+                    int32_t cl[4]; uint32_t clo[3], chi[3]; std::memcpy(cl, cq + 6, 16); std::memcpy(clo, cq + 10, 12); std::memcpy(chi, cq + 13, 12);
+                    // the child's own union box must be inside this child box (up to the grid steps of both levels)
+                    for (int a = 0; a < 3; a++)
+                    {
+                        double cmin = 1e300, cmax = -1e300;
+                        for (int k = 0; k < 4; k++)
+                        {
+                            const unsigned ql = (clo[a] >> (8 * k)) & 255u, qh = (chi[a] >> (8 * k)) & 255u;
+                            if (ql > qh) continue;
+                            cmin = std::min(cmin, (double)cq[a] + ql * (double)cq[3 + a]); cmax = std::max(cmax, (double)cq[a] + qh * (double)cq[3 + a]);
+                        }
+                        const double slack = (double)cq[3 + a] + (double)q[3 + a];
+                        if (cmin < box[a] - slack || cmax > box[3 + a] + slack) errors++;
+                    }
+                    return;
+                }
+                int code = ~l; int first = code >> 3, count = (code & 7) + 1;
+                if (first < 0 || first + count > n || count > leaf_max) { errors++; return; }
                 for (int k = first; k < first + count; k++)
                 {
                     int t = b.order[k];
@@ -45,18 +83,23 @@ static int check(const std::vector<float>& verts, int n, int max_depth, int leaf
                     for (int v = 0; v < 3; v++)
                         for (int a = 0; a < 3; a++)
                         {
-                            float x = verts[(size_t)t * 9 + v * 3 + a];
-                            if (!(x > box[c][a] && x < box[c][3 + a])) errors++;
+                            double x = verts[(size_t)t * 9 + v * 3 + a];
+                            if (!(x > box[a] && x < box[3 + a])) errors++;
                         }
                 }
-            }
+            };
+            inside(link[c]);
+            if (link[c] >= 0) { if (link[c] <= node) errors++; walk(link[c], depth + 1, used_here); }
         }
     };
-    walk(0, 1);
+    walk(0, 1, 0);
     for (int i = 0; i < n; i++) if (seen[i] != 1) errors++;
-    if (maxdepth != b.depth || b.depth > max_depth) errors++;
-    if (errors) { std::printf("FAIL %s: %ld errors (depth %d reported %d)\n", name, errors, maxdepth, b.depth); return 1; }
-    std::printf("ok %s: n=%d nodes=%d depth=%d pad=%g\n", name, n, b.num_nodes, b.depth, b.pad);
+    for (int k = 0; k < b.num_nodes; k++) if (visited[k] != 1) errors++;
+    if (maxdepth != b.depth) errors++;
+    if (maxneed != b.stack_need || b.stack_need > max_stack) errors++;
+    if (errors) { std::printf("FAIL %s: %ld errors (depth %d reported %d, stack %d reported %d)\n", name, errors, maxdepth, b.depth, maxneed, b.stack_need); return 1; }
+    std::printf("ok %s: n=%d nodes=%d depth=%d stack=%d children/node=%.2f pad=%g\n", name, n, b.num_nodes, b.depth, b.stack_need,
+                (double)children / b.num_nodes, b.pad);
     return 0;
 }
 

@@ -82,21 +82,25 @@ def _exchange_worker(rank, world, port, out_dir):
     mask = D.tile_owner_mask(W, H, rank, world)[::-1]
     mine = np.where(mask[..., None], full, 0.0).astype(np.float32)
     ok = []
-    for mode in ("gather", "reduce"):
-        local = torch.from_numpy(mine.reshape(-1).copy())
-        ex = D.AccumulatorExchange(local, dst=0, width=W, height=H, mode=mode)
-        assert ex.mode == mode
-        ex.start()
-        res = ex.wait()
-        # a second batch: the local accumulator has grown, the exchange object is re-used
-        local += torch.from_numpy(mine.reshape(-1))
-        ex.start()
-        res2 = ex.wait().clone()
-        if rank == 0:
-            ok += [np.array_equal(res2.numpy().reshape(H, W, 3), 2 * full)]
-    lens = [len(D.owned_float_index(W, H, r, world)) for r in range(world)]
+    local = torch.from_numpy(mine.reshape(-1).copy())
+    ex = D.HostPackedExchange(local, W, H, dst=0)                   # packing order = the library's ptk_packed_layout
+    ex.start()
+    res = ex.wait()
     if rank == 0:
-        ok += [sum(lens) == W * H * 3, len(set(lens)) > 1 or world == 1]          # complete, and uneven in this frame
+        ok += [np.array_equal(res.numpy().reshape(H, W, 3), full)]
+    # a second batch: the local accumulator has grown, the exchange object is re-used
+    local += torch.from_numpy(mine.reshape(-1))
+    ex.start()
+    res2 = ex.wait()
+    # the comparator: sum-reduce of the zero-padded buffers gives the same image bit for bit
+    red = D.gather_accumulator(local, dst=0)
+    if rank == 0:
+        ok += [np.array_equal(res2.numpy().reshape(H, W, 3), 2 * full), np.array_equal(red.numpy(), res2.numpy())]
+    if rank == 0:
+        from pbrpathtracer_amd import ptk
+        lens = [ptk.packed_floats(W, H, r, world) for r in range(world)]
+        valid = [int((ptk.packed_layout(W, H, r, world) >= 0).sum()) for r in range(world)]
+        ok += [sum(valid) == W * H * 3, all(n % 768 == 0 for n in lens), sum(lens) == 5 * 4 * 768]
         np.save(os.path.join(out_dir, "ok.npy"), np.array(ok))
     dist.barrier()
     dist.destroy_process_group()
@@ -104,9 +108,32 @@ def _exchange_worker(rank, world, port, out_dir):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_packed_gather_exchange(tmp_path, world):
-    """AccumulatorExchange: every rank sends only its owned values (uneven counts, padded to the longest) and rank 0
-    scatters them into place; equals the sum-reduce form and the single-rank image, also on re-use."""
+    """The packed gather in the NATIVE packing order (ptk_packed_layout, the order the device pack / unpack kernels are
+    tested against on the GPU): every rank sends the 768-float blocks of its owned tiles (uneven counts), rank 0
+    scatters them into place; equals the single-rank image and the sum-reduce form, also on re-use."""
     import torch.multiprocessing as mp
     port = 31500 + (os.getpid() % 2000) + world
     mp.spawn(_exchange_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert np.load(str(tmp_path / "ok.npy")).all()
+
+
+def test_packed_layout_matches_the_tile_map():
+    """ptk_packed_layout (host-only entry of libptk) against the Python mirror of the tile -> rank map."""
+    from pbrpathtracer_amd import distributed as D, ptk
+    for (w, h, world) in [(70, 50, 3), (1280, 720, 8), (16, 16, 2), (5, 5, 4), (33, 17, 1)]:
+        seen = np.zeros(w * h * 3, np.int32)
+        for r in range(world):
+            lay = ptk.packed_layout(w, h, r, world)
+            assert len(lay) == D.owned_tile_count(w, h, r, world) * 768
+            idx = lay[lay >= 0]
+            seen[idx] += 1
+            mask = D.tile_owner_mask(w, h, r, world)[::-1].reshape(-1)          # rows bottom-up like the accumulator
+            assert mask[idx // 3].all()
+            # inside a tile: row-major from the tile's top-left, RGB innermost
+            if len(lay) == 0:
+                continue                                        # a rank without tiles (16 x 16 frame, 2 ranks)
+            first = lay[:768].reshape(16, 16, 3)
+            on = first[..., 0] >= 0
+            assert (first[..., 1][on] == first[..., 0][on] + 1).all() and (first[..., 2][on] == first[..., 0][on] + 2).all()
+        assert (seen == 1).all()
+    assert ptk.load().ptk_packed_floats(0, 10, 0, 1) < 0 and ptk.load().ptk_packed_floats(10, 10, 2, 2) < 0

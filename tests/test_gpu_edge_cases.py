@@ -146,15 +146,14 @@ def test_flat_and_bvh_walks_agree(ctx, oracle_mod):
 def test_work_distribution_modes_agree(ctx, oracle_mod, golden, aperture):
     """How work reaches the lanes never changes a bit: persistent waves pulling items from the queues, one item
     per wave, batched queue pops, several generations of waves, other chunk sizes, tile shares - all equal the
-    oracle's accumulator (BVH and FLAT kernels, with and without the primary-hit cache / live-quadrant list),
-    and so does the wavefront formulation (walk stage / shade stage kernels over path queues; BVH scenes)."""
+    oracle's accumulator (BVH and FLAT kernels, with and without the primary-hit cache / live-quadrant list)."""
     z = load_golden(golden)
     arrays = scene_from_golden(z); cam = _cam(z, aperture)
     W, H, D, spp = 150, 70, 5, 24
     ref, ref8, got, got8 = _both(ctx, oracle_mod, arrays, cam, W, H, D, spp)
     assert np.array_equal(ref, got) and np.array_equal(ref8, got8)
-    defaults = {"persistent": -1, "generations": 0, "max_batch": 1, "chunk": 0, "tri_threshold": 4, "wavefront": 0, "wavefront_paths": float(48 << 20)}
-    for opts in ({"wavefront": 1}, {"wavefront": 1, "wavefront_paths": 65536.0, "chunk": 3}, {"persistent": 1}, {"persistent": 0}, {"persistent": 1, "max_batch": 7}, {"persistent": 1, "generations": 3, "chunk": 2},
+    defaults = {"persistent": -1, "generations": 0, "max_batch": 1, "chunk": 0, "tri_threshold": 4}
+    for opts in ({"persistent": 1}, {"persistent": 0}, {"persistent": 1, "max_batch": 7}, {"persistent": 1, "generations": 3, "chunk": 2},
                  {"persistent": 1, "chunk": 24}, {"persistent": 0, "chunk": 3}, {"persistent": 1, "tri_threshold": 0}, {"persistent": 1, "tri_threshold": 64}):
         for k, v in {**defaults, **opts}.items():
             ctx.set_option(k, v)

@@ -60,8 +60,9 @@ def test_render_matches_oracle(ctx, oracle_mod, kind):
     print(f"{kind}: rmse={rmse:.3e} exact={exact:.4f} max|d|={np.abs(tot_o - tot_g).max():.3e}")
     assert np.isfinite(tot_g).all()
     assert rmse <= RMSE_TOL
-    assert exact >= 0.99
-    assert np.mean(rgb_o == rgb_g) >= 0.99
+    # the north star's tolerance is the RMSE above; what the kernel actually delivers is bit-for-bit agreement
+    assert np.array_equal(tot_o, tot_g)
+    assert np.array_equal(rgb_o, rgb_g)
 
 
 def test_sample_batching_is_invisible(ctx, oracle_mod):
