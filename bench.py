@@ -288,6 +288,7 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
         ctx.render(first, spp, args.seed); first += spp
         t_ms, a_ms = ctx.last_kernel_ms()
         ev_ms.append(t_ms); acc_ms.append(a_ms)
+        passes = max(1, ctx.last_render_ms()[1] // 2)          # trace_kernel launches per step (the sample buffer bounds a launch)
     ctx.set_option("overlap", 1)
     for kv in args.opts.split(","):
         if kv.startswith("overlap="):
@@ -313,7 +314,8 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
     flat = ntri <= 16
     s = float(stats["samples"])
     per = {k: stats[k] / s for k in ("rays", "shadow_rays", "node_visits", "tri_tests", "hits_shaded", "tex_fetches")}
-    live_fraction = stats["gen_lanes"] / s                             # paths actually started (camera ray not a cached miss)
+    per["max_nodes_one_ray"] = stats["max_walk_nodes"]
+    live_fraction = stats["paths_started"] / s                         # paths actually traced (camera ray not a cached miss)
     nodes, depth, _ = ctx.bvh_info()
     node_boxes = ctx.node_width() if hasattr(ctx, "node_width") else 2
     # SURVEY.md §8(d4), its own record sizes and flop counts; a visited node here holds `node_boxes` child boxes =
@@ -331,7 +333,7 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
         try:
             tr = json.load(open(traffic_file))
             if tr.get("spp") == spp and tr.get("n_gpus", 1) == world:
-                traffic = tr["hbm_bytes_per_launch"] * tr.get("launches_per_step", 1)
+                traffic = tr["hbm_bytes_per_launch"] * passes            # per step = per launch x launches per step
                 traffic_src = tr.get("source")
                 cache = tr.get("cache")
         except Exception:
@@ -351,6 +353,7 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
     roofline.update({
         "traffic": traffic, "traffic_source": traffic_src,
         "kernel": "trace_kernel<FLAT>" if flat else "trace_kernel<BVH>", "kernel_ms_isolated": round(kernel_ms, 4),
+        "trace_launches_per_step": passes,
         "accumulate_kernel_ms": round(float(np.mean(acc_ms)), 4),
         "computed_from": "ms_per_step (timed region; consecutive launches overlap their tails, so a step is shorter than an isolated launch)",
         "valu": {"flops_per_sample": round(d4_flops, 1), "achieved_TFLOPs": round(valu_tflops, 2), "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4),

@@ -88,6 +88,7 @@ typedef struct ptk_stats {
     uint64_t gen_wave_execs, gen_lanes;            /* camera-ray block executions per wave, lanes generated */
     uint64_t tri_wave_execs, tri_lanes;            /* triangle-arm executions of the BVH walk per wave, lanes testing */
     uint64_t max_walk_nodes;                       /* most node records a single ray fetched (tail diagnostic) */
+    uint64_t paths_started;                        /* samples actually traced (the others: camera ray known to miss) */
 } ptk_stats;
 
 typedef struct ptk_ctx ptk_ctx;
@@ -99,6 +100,11 @@ void ptk_destroy(ptk_ctx* ctx);
 /* replaces BuildBVH (pathtracer.cpp:260-274, mesh.cpp:169-211): stages the scene, builds the
  * device BVH (own builder; closest hit is tree-independent) and uploads everything to HBM */
 int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene);
+
+/* SetMaterial after BuildBVH (pathtracer.cpp:243-258): the reference's triangles point into the loaded materials, so an
+ * edited material is used by the next RenderFrame() without a rebuild, while the light list stays as BuildBVH collected
+ * it.  Rewrites the material table and the lights' colours in place; counts and texture bindings must be the uploaded ones. */
+int ptk_update_materials(ptk_ctx* ctx, int32_t num_materials, const ptk_material* materials);
 
 /* SetCamera + SetProjection + SetCameraFocalDist + SetCameraAperture (pathtracer.cpp:333-360).
  * dir/up are normalised and focal/fovy clamped exactly as the reference setters do. */
@@ -136,7 +142,10 @@ int ptk_read_accum(ptk_ctx* ctx, float* host_out);
 int ptk_write_accum(ptk_ctx* ctx, const float* host_in, int samples);   /* resume from a saved accumulator */
 
 int ptk_samples(ptk_ctx* ctx);         /* GetSamples (pathtracer.cpp:362-365); thread-safe */
-int ptk_request_exit(ptk_ctx* ctx);    /* Exit (pathtracer.cpp:819-822); thread-safe; skips work not yet started */
+/* Exit (pathtracer.cpp:819-822); thread-safe.  Cuts the render in flight: passes whose kernels have not started are
+ * skipped whole (an aborted pass adds nothing to the accumulator), the sample count still advances as mSamples does;
+ * the next ptk_render clears the request, as RenderFrame() resets mExit on entry (pathtracer.cpp:742) */
+int ptk_request_exit(ptk_ctx* ctx);
 int ptk_synchronize(ptk_ctx* ctx);
 const char* ptk_last_error(ptk_ctx* ctx);
 

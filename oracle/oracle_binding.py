@@ -113,6 +113,7 @@ class Oracle:
         L.orc_rand_u01.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
         L.orc_sample_circle.argtypes = [C.c_float, C.c_float, _f]
         L.orc_bvh_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.orc_direct_illumination_tape.argtypes = [C.c_void_p, _f, _f, _f, _f, _f]
         self.arrays = normalise_arrays(arrays)
         self.desc = fill_desc(SceneDescC(), self.arrays)
         self.h = L.orc_create(C.byref(self.desc))
@@ -172,6 +173,12 @@ class Oracle:
         self.lib.orc_tex2d(self.h, tex, u, v, self._p(out))
         return out
 
+    def direct_illumination_tape(self, p, n, diffuse, tape3) -> np.ndarray:
+        out = np.zeros(3, np.float32)
+        a = [np.ascontiguousarray(x, np.float32) for x in (p, n, diffuse, tape3)]
+        self.lib.orc_direct_illumination_tape(self.h, *[self._p(x) for x in a], self._p(out))
+        return out
+
     def bvh_info(self):
         n = C.c_int32(); d = C.c_int32()
         self.lib.orc_bvh_info(self.h, C.byref(n), C.byref(d))
@@ -188,4 +195,6 @@ def lib():
     L.orc_rand_u01.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
     L.orc_sample_circle.argtypes = [C.c_float, C.c_float, _f]
     L.orc_primary_dirs.argtypes = [C.POINTER(CameraC), C.c_int, C.c_int, C.c_void_p]
+    L.orc_aabb_intersect.argtypes = [_f] * 4
+    L.orc_aabb_build.argtypes = [_f, C.c_int, _f]
     return L

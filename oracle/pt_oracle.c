@@ -694,6 +694,52 @@ void orc_sample_circle(float r1, float r2, float* out2)
     out2[0] = cs * radius; out2[1] = sn * radius;
 }
 
+/* AABB::Intersect, mesh.cpp:48-59, verbatim semantics: (min - ro) / rd with IEEE division (rd components may be 0),
+ * glm min/max = (y < x ? y : x) / (x < y ? y : x), no t-max, boxes behind the ray are NOT rejected.  The oracle's own
+ * traversal does not use it (its boxes only accelerate; closest hit is tree-independent) - this probe pins the row a5. */
+int orc_aabb_intersect(const float* bmin, const float* bmax, const float* ro, const float* rd)
+{
+    float t1[3], t2[3];
+    for (int a = 0; a < 3; a++)
+    {
+        float tmin = (bmin[a] - ro[a]) / rd[a], tmax = (bmax[a] - ro[a]) / rd[a];
+        t1[a] = tmax < tmin ? tmax : tmin;          /* glm::min(tMin, tMax) */
+        t2[a] = tmin < tmax ? tmax : tmin;          /* glm::max(tMin, tMax) */
+    }
+    float m01 = t1[0] < t1[1] ? t1[1] : t1[0];
+    float tNear = m01 < t1[2] ? t1[2] : m01;
+    float n01 = t2[1] < t2[0] ? t2[1] : t2[0];
+    float tFar = t2[2] < n01 ? t2[2] : n01;
+    return tNear >= tFar ? 0 : 1;
+}
+
+/* AABB::Build over n points then AABB::Check, mesh.cpp:6-46 (min/max start at +-(float)0xFFFF, mesh.h:13,63-64;
+ * Check inflates a zero-thickness axis by EPS) */
+void orc_aabb_build(const float* pts, int n, float* out6)
+{
+    const float INF_ = (float)0xFFFF;
+    float mn[3] = { INF_, INF_, INF_ }, mx[3] = { -INF_, -INF_, -INF_ };
+    for (int i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++)
+        {
+            float v = pts[i * 3 + a];
+            if (v < mn[a]) mn[a] = v;
+            if (v > mx[a]) mx[a] = v;
+        }
+    for (int a = 0; a < 3; a++) if (mn[a] == mx[a]) mx[a] += ORC_EPS;
+    for (int a = 0; a < 3; a++) { out6[a] = mn[a]; out6[3 + a] = mx[a]; }
+}
+
+/* DirectIllumimation (pathtracer.cpp:504-531) with its three draws taken from `tape3` */
+void orc_direct_illumination_tape(const orc_scene* s, const float* p, const float* n, const float* diffuse, const float* tape3, float* out3)
+{
+    rng_t rng; memset(&rng, 0, sizeof rng);
+    rng.tape = tape3; rng.tape_len = 3; rng.tape_pos = 0;
+    uint32_t ray = 0;
+    v3 c = direct_illumination(s, ld3(p), ld3(n), ld3(diffuse), &rng, &ray);
+    out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
+}
+
 void orc_render(const orc_scene* s, const orc_camera* cam, int W, int H, int D,
                 uint32_t first_sample, uint32_t spp, uint64_t seed, int rank, int world,
                 float* total, uint8_t* rgb8, int threads)

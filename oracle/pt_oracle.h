@@ -114,6 +114,9 @@ void orc_triangle_init(const float* in15, float* out9);
 void orc_sincos(float a, float* s, float* c);
 float orc_rand_u01(uint64_t seed, uint32_t pixel, uint32_t sample, int n);  /* n-th draw of a path */
 void orc_sample_circle(float r1, float r2, float* out2);
+int  orc_aabb_intersect(const float* bmin, const float* bmax, const float* ro, const float* rd);   /* AABB::Intersect */
+void orc_aabb_build(const float* pts, int n, float* out6);                                         /* AABB::Build + Check */
+void orc_direct_illumination_tape(const orc_scene* s, const float* p, const float* n, const float* diffuse, const float* tape3, float* out3);
 
 /* traversal statistics of the oracle's own BVH (diagnostics only) */
 void orc_bvh_info(const orc_scene* s, int32_t* nodes, int32_t* depth);

@@ -1332,6 +1332,9 @@ bool decode_hdr(const std::vector<unsigned char>& d, int& w, int& h, std::vector
                 int i = 0, nleft;
                 while ((nleft = width - i) > 0)
                 {
+                    // truncated file: past its end every byte reads as 0, a zero-length run that never advances - the
+                    // reference's stb spins forever here; a zero count INSIDE the data is a harmless no-op there and here
+                    if (r.pos >= r.n) return false;
                     int count = r.u8();
                     if (count > 128)
                     {

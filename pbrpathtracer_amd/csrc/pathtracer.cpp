@@ -175,6 +175,10 @@ struct PathTracer::Impl {
     bool need_reset = false;
     bool have_resolution = false;
     bool scene_uploaded = false;
+    // edits after BuildBVH: the reference's triangles point into the loaded materials, so they take effect at the next
+    // RenderFrame() without a rebuild (pathtracer.cpp:250-258); the light list stays as BuildBVH collected it (:267-273)
+    bool materials_dirty = false, textures_dirty = false, built_once = false;
+    std::vector<int32_t> built_lights;
     bool camera_dirty = true, frame_dirty = true;
 
     uint64_t seed = 0;
@@ -210,7 +214,7 @@ struct PathTracer::Impl {
             tex = new Image(file);                         // :155-160
             textures.push_back(tex);
         }
-        scene_uploaded = false;
+        textures_dirty = true;
     }
 };
 
@@ -297,7 +301,7 @@ void PathTracer::SetMaterial(int objId, int elementId, Material& material)
     material.metallicTex = cur.metallicTex;
     material.opacityTex = cur.opacityTex;
     m->objects[objId].elements[elementId].material = material;
-    m->scene_uploaded = false;
+    m->materials_dirty = true;
 }
 
 // pathtracer.cpp:260-274: (re)build the acceleration structure, bind materials, collect lights —
@@ -311,6 +315,9 @@ void PathTracer::BuildBVH()
     int rc = ptk_upload_scene(m->ctx, &d);
     m->note(rc);
     m->scene_uploaded = rc == PTK_OK;
+    m->built_lights = fs.lights;
+    m->built_once = m->built_once || rc == PTK_OK;
+    m->materials_dirty = m->textures_dirty = false;
 }
 
 void PathTracer::ResetImage() { m->need_reset = true; }                // :276-279
@@ -367,8 +374,26 @@ void PathTracer::RenderFrame() { RenderFrames(1); }                    // :741-8
 void PathTracer::RenderFrames(int count)
 {
     if (count <= 0) return;
+    if (!m->scene_uploaded && m->built_once && !m->triangles.empty())
+        m->error = "geometry changed after BuildBVH(): call BuildBVH() again before RenderFrame()";   // (the reference would chase dangling pointers)
     if (!m->scene_uploaded || !m->have_resolution || !m->ensure_ctx()) return;
     int rc;
+    if (m->materials_dirty || m->textures_dirty)
+    {
+        // SetMaterial / Set...TextureForElement after BuildBVH: seen by this frame, as in the reference
+        FlatScene fs;
+        flatten_scene(m->triangles, m->objects, fs);
+        fs.lights = m->built_lights;                                    // mLights is BuildBVH's (pathtracer.cpp:267-273)
+        if (m->textures_dirty)
+        {
+            ptk_scene_desc d = fs.desc();
+            rc = ptk_upload_scene(m->ctx, &d);                          // new texels: stage everything again
+        }
+        else rc = ptk_update_materials(m->ctx, (int32_t)fs.materials.size(), fs.materials.data());
+        m->note(rc);
+        if (rc != PTK_OK) return;
+        m->materials_dirty = m->textures_dirty = false;
+    }
     if (m->camera_dirty)
     {
         rc = ptk_set_camera(m->ctx, m->cam_pos, m->cam_dir, m->cam_up, m->focal, m->fovy, m->focal_dist, m->aperture);

@@ -33,6 +33,10 @@ struct ptk_ctx {
     uint32_t* d_texels = nullptr;
     int num_nodes = 0, num_tris = 0, num_lights = 0, bvh_depth = 0, bvh_stack = 0, num_leaf_tris = 0;
     bool have_scene = false;
+    // host copies kept for ptk_update_materials: what was uploaded, the texture index map, the light records
+    std::vector<ptk_material> h_materials;
+    std::vector<int32_t> h_texmap, h_light_material;
+    std::vector<float> h_lights;
 
     // camera (host copies, already normalised / clamped like the reference setters)
     float cam_pos[3] = { 0, 0, 0 }, cam_dir[3] = { 0, 0, 1 }, cam_up[3] = { 0, 1, 0 };
@@ -44,6 +48,7 @@ struct ptk_ctx {
     int width = 0, height = 0, max_depth = 3;                                 // pathtracer.cpp:15
     float4* d_primary = nullptr;
     float4* d_primary_hit = nullptr;  // primary-visibility cache (pinhole, no opacity textures)
+    float4* d_primary_rd = nullptr;   // ... and the camera ray's direction per pixel
     uint2* d_pixel_rng = nullptr;     // per pixel: (pixel key, PCG increment) for pixel_rng_seed
     uint64_t pixel_rng_seed = 0; bool pixel_rng_valid = false;
     bool primary_hit_dirty = true, scene_has_opacity = false;
@@ -137,6 +142,27 @@ void normalize3(const float* in, float* out)
     float sqr = in[0] * in[0] + in[1] * in[1] + in[2] * in[2];
     float inv = 1.0f / std::sqrt(sqr);
     out[0] = in[0] * inv; out[1] = in[1] * inv; out[2] = in[2] * inv;
+}
+
+// device material record (ptk_device.h) from the boundary's ptk_material
+void pack_material(const ptk_material& m, const std::vector<int32_t>& texmap, float* q)
+{
+    q[0] = m.diffuse[0]; q[1] = m.diffuse[1]; q[2] = m.diffuse[2]; q[3] = as_float(m.type != 0 ? 1 : 0);
+    q[4] = m.specular[0]; q[5] = m.specular[1]; q[6] = m.specular[2]; q[7] = m.emissive_intensity;
+    q[8] = m.emissive[0]; q[9] = m.emissive[1]; q[10] = m.emissive[2]; q[11] = m.roughness;
+    // Russian-roulette probability, pathtracer.cpp:589: glm::min(0.95f, glm::max(glm::max(d.x, d.y), d.z))
+    float mx = m.diffuse[0] < m.diffuse[1] ? m.diffuse[1] : m.diffuse[0];
+    mx = mx < m.diffuse[2] ? m.diffuse[2] : mx;
+    float prob = 0.95f < mx ? 0.95f : mx;
+    q[12] = m.reflectiveness; q[13] = m.translucency; q[14] = m.ior; q[15] = prob;
+    int any = 0;
+    for (int k = 0; k < 6; k++)
+    {
+        int32_t t = m.tex[k] >= 0 ? texmap[m.tex[k]] : -1;
+        q[16 + k] = as_float(t);
+        if (t >= 0) any = 1;
+    }
+    q[22] = as_float(any); q[23] = 0.0f;
 }
 
 // image-plane set-up of RenderFrame, pathtracer.cpp:755-766 (host, once per camera/resolution change)
@@ -246,13 +272,13 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
     {
         if (c->primary_hit_dirty)
         {
-            launch_primary_hits(p, c->d_primary_hit, c->stream);
+            launch_primary_hits(p, c->d_primary_hit, c->d_primary_rd, c->stream);
             HIPCHK(c, hipGetLastError());
             c->primary_hit_dirty = false;
             c->hit_generation++;
             c->inputs_dirty = true;
         }
-        p.primary_hit = c->d_primary_hit;
+        p.primary_hit = c->d_primary_hit; p.primary_rd = c->d_primary_rd;
     }
     if (!c->pixel_rng_valid || c->pixel_rng_seed != seed)
     {
@@ -431,7 +457,7 @@ void ptk_destroy(ptk_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_mats); dfree(c->d_lights);
-    dfree(c->d_texinfo); dfree(c->d_texels); dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_accum); dfree(c->d_rgb8);
+    dfree(c->d_texinfo); dfree(c->d_texels); dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_primary_rd); dfree(c->d_accum); dfree(c->d_rgb8);
     dfree(c->d_pixel_rng);
     for (int b = 0; b < 2; b++)
     {
@@ -533,27 +559,7 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     if (texels.size() >= (1ull << 31)) return fail(c, PTK_ERR_LIMIT, "texel atlas too large");
 
     std::vector<float> mats((size_t)s->num_materials * MAT_F4 * 4, 0.0f);
-    for (int32_t i = 0; i < s->num_materials; i++)
-    {
-        const ptk_material& m = s->materials[i];
-        float* q = mats.data() + (size_t)i * MAT_F4 * 4;
-        q[0] = m.diffuse[0]; q[1] = m.diffuse[1]; q[2] = m.diffuse[2]; q[3] = as_float(m.type != 0 ? 1 : 0);
-        q[4] = m.specular[0]; q[5] = m.specular[1]; q[6] = m.specular[2]; q[7] = m.emissive_intensity;
-        q[8] = m.emissive[0]; q[9] = m.emissive[1]; q[10] = m.emissive[2]; q[11] = m.roughness;
-        // Russian-roulette probability, pathtracer.cpp:589: glm::min(0.95f, glm::max(glm::max(d.x, d.y), d.z))
-        float mx = m.diffuse[0] < m.diffuse[1] ? m.diffuse[1] : m.diffuse[0];
-        mx = mx < m.diffuse[2] ? m.diffuse[2] : mx;
-        float prob = 0.95f < mx ? 0.95f : mx;
-        q[12] = m.reflectiveness; q[13] = m.translucency; q[14] = m.ior; q[15] = prob;
-        int any = 0;
-        for (int k = 0; k < 6; k++)
-        {
-            int32_t t = m.tex[k] >= 0 ? texmap[m.tex[k]] : -1;
-            q[16 + k] = as_float(t);
-            if (t >= 0) any = 1;
-        }
-        q[22] = as_float(any); q[23] = 0.0f;
-    }
+    for (int32_t i = 0; i < s->num_materials; i++) pack_material(s->materials[i], texmap, mats.data() + (size_t)i * MAT_F4 * 4);
 
     std::vector<float> tris((size_t)n * TRI_F4 * 4, 0.0f);
     c->num_leaf_tris = n;
@@ -620,8 +626,44 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     c->scene_has_opacity = false;
     for (int32_t i = 0; i < n; i++)
         if (s->materials[s->material[i]].tex[5] >= 0) { c->scene_has_opacity = true; break; }
+    c->h_materials.assign(s->materials, s->materials + s->num_materials);
+    c->h_texmap = texmap;
+    c->h_lights = lights;
+    c->h_light_material.resize(s->num_lights);
+    for (int32_t k = 0; k < s->num_lights; k++) c->h_light_material[k] = s->material[s->lights[k]];
     c->primary_hit_dirty = true;
     c->have_scene = true;
+    c->inputs_dirty = true;
+    return PTK_OK;
+}
+
+// Material edits after BuildBVH: in the reference `Triangle::mat` points into mLoadedObjects, so a SetMaterial is seen by
+// the very next RenderFrame() without a rebuild, while the light LIST stays the one BuildBVH collected
+// (pathtracer.cpp:250-258, :267-273, :528).  Same here: the material table and the lights' colours are rewritten in
+// place; geometry, BVH, textures and the light list are untouched.  Texture bindings must be the uploaded ones.
+int ptk_update_materials(ptk_ctx* c, int32_t num_materials, const ptk_material* materials)
+{
+    if (!c || !materials) return PTK_ERR_BAD_ARG;
+    if (!c->have_scene) return fail(c, PTK_ERR_BAD_ARG, "ptk_upload_scene has not been called");
+    if (num_materials != (int32_t)c->h_materials.size()) return fail(c, PTK_ERR_BAD_ARG, "material count differs from the uploaded scene");
+    for (int32_t i = 0; i < num_materials; i++)
+        for (int k = 0; k < 6; k++)
+            if (materials[i].tex[k] != c->h_materials[i].tex[k])
+                return fail(c, PTK_ERR_BAD_ARG, "texture bindings changed: upload the scene again");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<float> mats((size_t)num_materials * MAT_F4 * 4, 0.0f);
+    for (int32_t i = 0; i < num_materials; i++) pack_material(materials[i], c->h_texmap, mats.data() + (size_t)i * MAT_F4 * 4);
+    for (size_t k = 0; k < c->h_light_material.size(); k++)
+    {
+        const ptk_material& m = materials[c->h_light_material[k]];
+        float* q = c->h_lights.data() + k * LIGHT_F4 * 4;
+        q[7] = m.emissive[0] * m.emissive_intensity; q[11] = m.emissive[1] * m.emissive_intensity; q[12] = m.emissive[2] * m.emissive_intensity;
+    }
+    // behind everything already queued (stream-ordered): renders in flight keep the old table
+    if (!mats.empty()) HIPCHK(c, hipMemcpyAsync(c->d_mats, mats.data(), mats.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (!c->h_lights.empty()) HIPCHK(c, hipMemcpyAsync(c->d_lights, c->h_lights.data(), c->h_lights.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // the host vectors above go out of scope
+    c->h_materials.assign(materials, materials + num_materials);
     c->inputs_dirty = true;
     return PTK_OK;
 }
@@ -653,11 +695,12 @@ int ptk_set_frame(ptk_ctx* c, int width, int height, int max_depth)
     if (width != c->width || height != c->height || !c->d_accum)
     {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_accum); dfree(c->d_rgb8); dfree(c->d_pixel_rng);
+        dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_primary_rd); dfree(c->d_accum); dfree(c->d_rgb8); dfree(c->d_pixel_rng);
         c->pixel_rng_valid = false;
         size_t px = (size_t)width * height;
         HIPCHK(c, hipMalloc(&c->d_primary, px * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->d_primary_hit, px * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_primary_rd, px * sizeof(float4)));
         HIPCHK(c, hipMalloc(&c->d_pixel_rng, px * sizeof(uint2)));
         HIPCHK(c, hipMalloc(&c->d_accum, px * 3 * sizeof(float)));
         HIPCHK(c, hipMalloc(&c->d_rgb8, px * 3));
@@ -703,13 +746,11 @@ int ptk_render(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uint64_t s
     c->last_launches = 0;
     c->timed = false;
     if (spp_count == 0) return PTK_OK;
-    if (c->exit_req.load())
-    {
-        // Exit() before the frame started: the frame's work is skipped but the count still advances
-        // (mSamples++ precedes the loop and is not rolled back, pathtracer.cpp:753, :779-780)
-        c->samples = (int)(first_sample + spp_count);
-        return PTK_OK;
-    }
+    // RenderFrame() begins with mExit = false (pathtracer.cpp:742): an Exit() only cuts the frame(s) in flight, the next
+    // call renders again.  Stream-ordered, so a render still running keeps seeing the flag it was aborted with.
+    c->exit_req = 0;
+    HIPCHK(c, hipMemsetAsync(c->d_exit, 0, sizeof(uint32_t), c->stream));
+    c->inputs_dirty = true;
     int rc = ensure_primary(c);
     if (rc != PTK_OK) return rc;
     rc = run_passes(c, first_sample, spp_count, seed, false, accum_ptr(c), c->d_rgb8, c->d_exit, true);
@@ -747,7 +788,7 @@ int ptk_collect_stats(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uin
     out->walk_wave_iters = h[7]; out->walk_lane_iters = h[8]; out->shade_wave_execs = h[9]; out->shade_lanes = h[10];
     out->gen_wave_execs = h[11]; out->gen_lanes = h[12];
     out->tri_wave_execs = h[13]; out->tri_lanes = h[14];
-    out->max_walk_nodes = h[15];
+    out->max_walk_nodes = h[15]; out->paths_started = h[0];
     return PTK_OK;
 }
 

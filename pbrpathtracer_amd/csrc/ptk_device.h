@@ -74,6 +74,7 @@ struct RenderParams {
     const float4* primary;      // [H][W] unit primary directions before DOF (top-down rows)
     const uint2* pixel_rng;     // [H][W] (pixel key, PCG increment) of the pixel's RNG streams for this launch's seed
     const float4* primary_hit;  // [H][W] (bits tri | PTK_NOHIT, t, u, v) of the camera ray, or null when not cacheable
+    const float4* primary_rd;   // [H][W] its unit direction (valid with primary_hit)
     float* accum;               // [H][W][3] float RGB, rows bottom-up (mTotalImg)
     uint8_t* rgb8;              // [H][W][3] RGB8, rows bottom-up (mOutImg)
     const uint32_t* exit_flag;
@@ -119,7 +120,7 @@ void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t strea
 void launch_pack_owned(const float* accum, float* packed, int width, int height, int rank, int world, hipStream_t stream);
 void launch_unpack_all(const float* packed, const long long* bases, float* image, int width, int height, int world, hipStream_t stream);
 void launch_primary(const PrimaryParams& p, hipStream_t stream);
-void launch_primary_hits(const RenderParams& p, float4* out, hipStream_t stream);
+void launch_primary_hits(const RenderParams& p, float4* out, float4* out_rd, hipStream_t stream);
 void launch_probe(const ProbeParams& p, hipStream_t stream);
 
 }  // namespace ptk

@@ -54,6 +54,9 @@ namespace ptk {
 #define PTK_TRACE_WAVES_BVH 4       // ... BVH variant
 #endif
 #define PTK_NOHIT 0x7fffffff
+#ifndef PTK_GEN_CACHED_FAST
+#define PTK_GEN_CACHED_FAST 1        // cached camera hits: the camera-ray block only loads the pixel's direction and hit
+#endif
 
 struct v3 { float x, y, z; };
 
@@ -164,7 +167,7 @@ __device__ __forceinline__ float tex2d_r(const PT& P, int tex, float uvx, float 
 
 struct Hit { int tri; float t, u, v; };
 
-struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex, walk_iters, walk_lanes, shade_execs, shade_lanes, gen_execs, gen_lanes, tri_execs, tri_lanes, cur_nodes, max_nodes; };
+struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex, walk_iters, walk_lanes, shade_execs, shade_lanes, gen_execs, gen_lanes, tri_execs, tri_lanes, cur_nodes, max_nodes, started; };
 
 // ---- closest hit (replaces the recursive PathTracer::Hit, pathtracer.cpp:411-492) ---------------------
 // The walk is re-entrant: all of its state lives in this struct so a wave can interleave BVH steps
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
     const v3 camRight = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
     const v3 camUp = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
 
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     Rng rng;
     rng.inc = 1u; rng.state = 0; rng.key = 0;
 
@@ -949,36 +952,53 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 rng.inc = pr.y;
                 rng.state = hash32(P.first_sample + sample_abs + pkey);
                 rng.key = rng.state;
-                // per-pixel constants are re-read here (L1/L2 hits) instead of living in registers
-                const float4 d0 = P.primary[pix];
-                const v3 dir0 = V(d0.x, d0.y, d0.z);
-                v3 focalPoint = add(camPos0, muls(dir0, P.focal_dist));
-                float r1 = rng.next(), r2 = rng.next();          // always two draws, even with a pinhole
-                v3 ro = camPos0;
-                if (P.aperture != 0.0f)
-                {
-                    float angle = (float)((double)r1 * 2. * PTK_PI_D);
-                    float radius = sqrtf(r2);
-                    float sn, cs;
-                    sincos_2pi(angle, sn, cs);
-                    float offx = (cs * radius) * P.aperture, offy = (sn * radius) * P.aperture;
-                    ro = add(camPos0, add(muls(camRight, offx), muls(camUp, offy)));
-                }
-                v3 rd = normalize(sub(focalPoint, ro));
                 L = V(0.0f, 0.0f, 0.0f); T = V(1.0f, 1.0f, 1.0f);
                 depth = 0; iter = 0; inside = false; ray = 0;
                 W.occl_tri = -1;
-                W.begin(ro, rd, P.num_nodes);
-                st = ST_TRAV;
-                if (P.primary_hit)
+                if (STATS) cnt.started++;
+                if (PTK_GEN_CACHED_FAST && P.primary_hit)
                 {
-                    // pinhole camera, no stochastic opacity: every sample of this pixel shoots the same
-                    // primary ray, so its closest hit was computed once by primary_hits_kernel
-                    const float4 c = P.primary_hit[pix];
+                    // Pinhole camera, no stochastic opacity: every sample of this pixel shoots the same camera ray, so its
+                    // direction and closest hit were computed once (primary_hits_kernel) and the path starts at its first
+                    // surface interaction.  The two SampleCircle draws a pinhole frame still consumes (pathtracer.cpp:787,
+                    // always two) only advance the stream - two LCG steps in one:
+                    //   s2 = (s * a + inc) * a + inc = s * a^2 + inc * (a + 1)      (mod 2^32: the identical state)
+                    rng.state = rng.state * (747796405u * 747796405u) + rng.inc * (747796405u + 1u);
+                    const float4 c = P.primary_hit[pix], r = P.primary_rd[pix];
+                    W.ro = camPos0; W.rd = V(r.x, r.y, r.z);
                     W.best.tri = __float_as_int(c.x); W.best.t = c.y; W.best.u = c.z; W.best.v = c.w;
-                    W.node = NODE_EXIT;
+                    W.node = NODE_EXIT; W.sp = 0; W.tri_left = 0;
                     ray = 1;
-                    st = ST_SHADE;              // (pixels whose primary ray misses never get here)
+                    st = ST_SHADE;              // (pixels whose camera ray misses never get here)
+                }
+                else
+                {
+                    // per-pixel constants are re-read here (L1/L2 hits) instead of living in registers
+                    const float4 d0 = P.primary[pix];
+                    const v3 dir0 = V(d0.x, d0.y, d0.z);
+                    v3 focalPoint = add(camPos0, muls(dir0, P.focal_dist));
+                    float r1 = rng.next(), r2 = rng.next();          // always two draws, even with a pinhole
+                    v3 ro = camPos0;
+                    if (P.aperture != 0.0f)
+                    {
+                        float angle = (float)((double)r1 * 2. * PTK_PI_D);
+                        float radius = sqrtf(r2);
+                        float sn, cs;
+                        sincos_2pi(angle, sn, cs);
+                        float offx = (cs * radius) * P.aperture, offy = (sn * radius) * P.aperture;
+                        ro = add(camPos0, add(muls(camRight, offx), muls(camUp, offy)));
+                    }
+                    v3 rd = normalize(sub(focalPoint, ro));
+                    W.begin(ro, rd, P.num_nodes);
+                    st = ST_TRAV;
+                    if (P.primary_hit)
+                    {
+                        const float4 c = P.primary_hit[pix];
+                        W.best.tri = __float_as_int(c.x); W.best.t = c.y; W.best.u = c.z; W.best.v = c.w;
+                        W.node = NODE_EXIT;
+                        ray = 1;
+                        st = ST_SHADE;
+                    }
                 }
             }
         }
@@ -987,6 +1007,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
 #undef PTK_FINISH_PATH
     if (STATS)
     {
+        atomicAdd(&P.stats[0], (unsigned long long)cnt.started);
         atomicAdd(&P.stats[1], (unsigned long long)cnt.rays);
         atomicAdd(&P.stats[2], (unsigned long long)cnt.shadow);
         atomicAdd(&P.stats[3], (unsigned long long)cnt.nodes);
@@ -1013,6 +1034,9 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
 // (pathtracer.cpp:802-812).  One thread per pixel; each sample read is a coalesced 1 KiB per wave.
 __global__ __launch_bounds__(PTK_BLOCK) void accumulate_kernel(const RenderParams P)
 {
+    // an aborted pass adds nothing: trace waves that saw the exit flag returned without writing their samples, so the
+    // sample buffer may hold another pass's values (the reference adds nothing for the rows it skips, pathtracer.cpp:779-780)
+    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, quad = tid >> 6;
     const int owned = blockIdx.x;
@@ -1083,13 +1107,13 @@ __global__ void primary_dirs_kernel(const PrimaryParams P)
 // Primary-visibility cache for pinhole cameras (aperture == 0) in scenes without opacity textures: the
 // camera ray of a pixel is the same for every sample (pathtracer.cpp:785-791 with a zero lens offset),
 // so its closest hit is found once per camera / scene change instead of once per sample.
-__global__ __launch_bounds__(PTK_BLOCK) void primary_hits_kernel(const RenderParams P, float4* out)
+__global__ __launch_bounds__(PTK_BLOCK) void primary_hits_kernel(const RenderParams P, float4* out, float4* out_rd)
 {
     __shared__ int lds_stack[PTK_MAX_BVH_DEPTH * PTK_BLOCK];
     const int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (i >= P.width * P.height) return;
     Rng rng; rng.inc = 1u; rng.state = 0u; rng.key = 0u;            // no opacity draws can occur here
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     float4 d = P.primary[i];
     const v3 camPos0 = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
     v3 focalPoint = add(camPos0, muls(V(d.x, d.y, d.z), P.focal_dist));
@@ -1099,6 +1123,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void primary_hits_kernel(const RenderPar
     W.begin(camPos0, rd, P.num_nodes);
     while (!W.done()) walk_step<false, PTK_BLOCK>(P, W, rng, 0u, lds_stack + threadIdx.x, cnt);
     out[i] = make_float4(__int_as_float(W.best.tri), W.best.t, W.best.u, W.best.v);
+    out_rd[i] = make_float4(rd.x, rd.y, rd.z, 0.0f);           // the very floats the camera-ray block computes for a zero lens offset
 }
 
 // Parity probe: closest hit for a list of rays (no opacity draws differ: key 0, ray 0).
@@ -1108,7 +1133,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_hits_kernel(const ProbeParams
     int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
     if (i >= P.n) return;
     Rng rng; rng.inc = (hash32(0u ^ 0x9E3779B9u) << 1) | 1u; rng.state = hash32(0u); rng.key = rng.state;
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     v3 ro = V(P.ro[i * 3], P.ro[i * 3 + 1], P.ro[i * 3 + 2]);
     v3 rd = V(P.rd[i * 3], P.rd[i * 3 + 1], P.rd[i * 3 + 2]);
     Walk W;
@@ -1283,10 +1308,10 @@ void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t strea
     if (owned_tiles <= 0) return;
     hipLaunchKernelGGL(accumulate_kernel, dim3(owned_tiles), dim3(PTK_BLOCK), 0, stream, p);
 }
-void launch_primary_hits(const RenderParams& p, float4* out, hipStream_t stream)
+void launch_primary_hits(const RenderParams& p, float4* out, float4* out_rd, hipStream_t stream)
 {
     int n = p.width * p.height;
-    hipLaunchKernelGGL(primary_hits_kernel, dim3((n + PTK_BLOCK - 1) / PTK_BLOCK), dim3(PTK_BLOCK), 0, stream, p, out);
+    hipLaunchKernelGGL(primary_hits_kernel, dim3((n + PTK_BLOCK - 1) / PTK_BLOCK), dim3(PTK_BLOCK), 0, stream, p, out, out_rd);
 }
 void launch_primary(const PrimaryParams& p, hipStream_t stream)
 {

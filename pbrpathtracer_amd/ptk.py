@@ -13,7 +13,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptk.so")
+# (PTK_LIB_PATH: developer knob for A/B builds of the kernels, tools/ab.sh; the product loads the in-tree library)
+LIB_PATH = os.environ.get("PTK_LIB_PATH") or os.path.join(_HERE, "libptk.so")
 
 PTK_OK = 0
 PTK_TILE = 16
@@ -43,7 +44,7 @@ class Stats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
                 ("samples", "rays", "shadow_rays", "node_visits", "tri_tests", "hits_shaded", "tex_fetches",
                  "walk_wave_iters", "walk_lane_iters", "shade_wave_execs", "shade_lanes", "gen_wave_execs", "gen_lanes",
-                 "tri_wave_execs", "tri_lanes", "max_walk_nodes")]
+                 "tri_wave_execs", "tri_lanes", "max_walk_nodes", "paths_started")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -57,7 +58,7 @@ _lib = None
 
 # every symbol include/ptk.h declares
 SYMBOLS = [
-    "ptk_create", "ptk_destroy", "ptk_upload_scene", "ptk_set_camera", "ptk_set_frame", "ptk_set_tile",
+    "ptk_create", "ptk_destroy", "ptk_upload_scene", "ptk_update_materials", "ptk_set_camera", "ptk_set_frame", "ptk_set_tile",
     "ptk_reset", "ptk_render", "ptk_resolve_rgb8", "ptk_read_accum", "ptk_write_accum", "ptk_samples",
     "ptk_request_exit", "ptk_synchronize", "ptk_last_error", "ptk_accum_device_ptr", "ptk_rgb8_device_ptr",
     "ptk_bind_accum", "ptk_set_stream", "ptk_gather_accum", "ptk_set_option", "ptk_last_render_ms",
@@ -82,6 +83,7 @@ def load() -> C.CDLL:
     L.ptk_create.argtypes = [C.POINTER(vp), i32]
     L.ptk_destroy.argtypes = [vp]; L.ptk_destroy.restype = None
     L.ptk_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.ptk_update_materials.argtypes = [vp, i32, vp]
     L.ptk_set_camera.argtypes = [vp, fp, fp, fp, f32, f32, f32, f32]
     L.ptk_set_frame.argtypes = [vp, i32, i32, i32]
     L.ptk_set_tile.argtypes = [vp, i32, i32]
@@ -184,6 +186,10 @@ class Context:
         a = normalise_arrays(arrays)
         d = scene_desc(a)
         self._chk(self.L.ptk_upload_scene(self.h, C.byref(d)), "ptk_upload_scene")
+
+    def update_materials(self, materials: np.ndarray):
+        m = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
+        self._chk(self.L.ptk_update_materials(self.h, len(m), m.ctypes.data), "ptk_update_materials")
 
     def set_camera(self, pos, dir, up, focal, fovy, focal_dist, aperture):
         f3 = C.c_float * 3

@@ -127,14 +127,20 @@ def test_exact_pinhole_primary_cache(tmp_path, oracle_mod, cfg, kw, spp):
 
 def test_exit_from_another_thread(tmp_path):
     """Exit() / GetSamples() are called from the UI thread while the render thread is inside RenderFrame
-    (main.cpp:1153, :2277-2324): must be safe; work not yet started is skipped, mSamples still advances."""
+    (main.cpp:1153, :2277-2324): must be safe.  Exit() cuts the render in flight - whole passes are skipped, an aborted
+    pass adds NOTHING (the accumulator is a prefix of the passes, bit for bit), mSamples still advances - and the next
+    RenderFrame() renders again without a ResetImage(), as the reference resets mExit on entry (pathtracer.cpp:742)."""
     import threading
     import time
     from pbrpathtracer_amd import scenes as S
     from pbrpathtracer_amd.pathtracer import PathTracer
     pts, scene, _ = S.build_config("C4", str(tmp_path), width=640, height=360, grid=60)
-    pt = PathTracer(0); pt.LoadSceneFile(pts)
+    pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(5)
     pt.RenderFrames(1)
+    ctx = pt.context()
+    # small passes so that the 2048-sample render is many launches: 640x360 -> 920 tiles x 4 x 64 x 16 B = 3.8 MB per sample
+    ctx.set_option("pass_bytes", float(32 << 20))            # 8 samples per pass
+    pt.ResetImage()
     seen = []
     stop = threading.Event()
 
@@ -143,16 +149,55 @@ def test_exit_from_another_thread(tmp_path):
             seen.append(pt.GetSamples())
             time.sleep(0.0005)
     t = threading.Thread(target=ui); t.start()
-    killer = threading.Timer(0.01, pt.Exit); killer.start()
+    killer = threading.Timer(0.02, pt.Exit); killer.start()
     t0 = time.time()
     pt.RenderFrames(2048)                                   # long enough for Exit() to land mid-render
     dt = time.time() - t0
     stop.set(); t.join(); killer.join()
-    assert pt.GetSamples() == 2049 and pt.LastError() == ""
-    assert np.isfinite(pt.ReadAccumulation()).all()
-    pt.ResetImage(); pt.RenderFrames(2)                     # Exit is cleared by ResetImage: rendering resumes
-    assert pt.GetSamples() == 2 and pt.ReadAccumulation().any()
-    print(f"render with Exit() after 10 ms took {dt*1e3:.1f} ms, UI polled {len(seen)} times")
+    assert pt.GetSamples() == 2048 and pt.LastError() == ""
+    aborted = pt.ReadAccumulation()
+    assert np.isfinite(aborted).all()
+    # which prefix of the 8-sample passes made it?  render them again on a second tracer and compare bit for bit
+    ref = PathTracer(0); ref.LoadSceneFile(pts); ref.SetSeed(5); ref.RenderFrames(1); ref.ResetImage()
+    ref.context().set_option("pass_bytes", float(32 << 20))
+    done, match = 0, np.array_equal(aborted, np.zeros_like(aborted))
+    while not match and done < 2048:
+        ref.RenderFrames(8); done += 8
+        match = np.array_equal(ref.ReadAccumulation(), aborted)
+    assert match, "the aborted render is not a whole number of passes"
+    print(f"Exit() after 20 ms: {done} of 2048 samples were accumulated, render call took {dt*1e3:.1f} ms, UI polled {len(seen)} times")
+    # ... and the next frame renders again, WITHOUT ResetImage: samples 2048.. are added on top
+    pt.RenderFrames(8)
+    assert pt.GetSamples() == 2056
+    resumed = pt.ReadAccumulation()
+    assert not np.array_equal(resumed, aborted) and np.isfinite(resumed).all()
+    ref2 = PathTracer(0); ref2.LoadSceneFile(pts); ref2.SetSeed(5); ref2.RenderFrames(1); ref2.ResetImage()
+    ref2.context().reset(); ref2.context().render(2048, 8, 5)
+    assert np.array_equal((resumed - aborted)[aborted == 0], ref2.ReadAccumulation()[aborted == 0])   # exact where nothing was added before
+    pt.close(); ref.close(); ref2.close()
+
+
+def test_material_edits_after_build_take_effect(tmp_path, oracle_mod):
+    """SetMaterial after BuildBVH: the reference's triangles point into the loaded materials, so the next RenderFrame()
+    uses the edited values without a rebuild (pathtracer.cpp:243-258) while the light list stays BuildBVH's.  Here the
+    material table is rewritten in place (ptk_update_materials); geometry edits after BuildBVH are reported."""
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer
+    pts, scene, _ = S.build_config("C1", str(tmp_path), width=96, height=64, depth=4)
+    pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(2)
+    pt.RenderFrames(4)
+    before = pt.ReadAccumulation()
+    # paint the first element blue and make it half mirror: (type, diffuse, specular, emissive, I, roughness, reflectiveness, translucency, ior)
+    pt.SetMaterial(0, 0, np.array([0, 0.1, 0.2, 0.9, 1, 1, 1, 0, 0, 0, 1, 0.0, 0.5, 1.0, 1.5], np.float32))
+    pt.ResetImage(); pt.RenderFrames(4)
+    assert pt.LastError() == ""
+    edited = pt.ReadAccumulation()
+    assert not np.array_equal(before, edited)
+    # the same scene staged afresh with that material gives the same image: oracle on the re-staged arrays
+    o, ocam = _oracle_for(oracle_mod, pt, scene)
+    W, H = pt.GetResolution()
+    ref, _ = o.render(ocam, W, H, pt.GetTraceDepth(), 0, 4, 2)
+    assert np.array_equal(edited, ref)
     pt.close()
 
 
@@ -179,11 +224,11 @@ def test_page_locked_handoff_buffer(tmp_path):
     assert frames[0].any() and np.array_equal(frames[0], frames[1])
 
 
-@pytest.mark.parametrize("cfg,world", [("C2", 97), ("C3", 149), ("C4", 499), ("C5", 1999)])
+@pytest.mark.parametrize("cfg,world", [("C1", 1), ("C2", 97), ("C3", 149), ("C4", 499), ("C5", 1999)])
 def test_full_size_spot_check_against_oracle(tmp_path, oracle_mod, cfg, world):
     """The BASELINE configs at their FULL size and sample count (persistent waves, live-quadrant list, two passes for
     C4): the oracle renders the tiles of one rank of a `world`-way split (a few dozen of the frame's tiles, spread
-    over it) and the GPU's accumulator must equal it there bit for bit."""
+    over it; C1, the reference's CPU-runnable case, whole) and the GPU's accumulator must equal it there bit for bit."""
     from pbrpathtracer_amd import scenes as S
     from pbrpathtracer_amd import distributed as D
     from pbrpathtracer_amd.pathtracer import PathTracer
@@ -205,6 +250,39 @@ def test_full_size_spot_check_against_oracle(tmp_path, oracle_mod, cfg, world):
     mask = D.tile_owner_mask(W, H, rank, world)[::-1]           # accumulator rows are bottom-up
     assert mask.sum() >= 16 * 16 * 4 and ref[mask].any()
     assert np.array_equal(got[mask], ref[mask])
+    pt.close()
+
+
+def test_c5_tile_split_over_8_ranks_on_one_gpu(tmp_path, oracle_mod):
+    """BASELINE configs[4]'s shape - the 1 M-triangle frame tile-split over 8 ranks and gathered - with this one GPU playing
+    every rank in turn: each rank's share is rendered (ptk_set_tile), packed by the exchange's pack kernel, and the eight
+    packed buffers are scattered by its unpack kernel; the result equals the single-GPU frame bit for bit, and the
+    oracle confirms a spread of its tiles.  (Samples per pixel reduced to 32: the split, not the sample count, is the subject.)"""
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd import distributed as D
+    from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
+    pts, scene, _ = S.build_config("C5", str(tmp_path))
+    spp = 32
+    pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(8); pt.SetCameraAperture(0.0)
+    W, H = pt.GetResolution(); Dp = pt.GetTraceDepth()
+    pt.RenderFrames(spp)
+    whole = pt.ReadAccumulation()
+    ctx = pt.context()
+    packed = []
+    for r in range(8):
+        ctx.set_tile(r, 8); ctx.reset(); ctx.render(0, spp, 8)
+        part = ctx.read_accum()
+        mask = D.tile_owner_mask(W, H, r, 8)[::-1]
+        assert not part[~mask].any() and np.array_equal(part[mask], whole[mask])
+        packed.append(ctx.probe_pack(r, 8))
+    ctx.set_tile(0, 1)
+    assert np.array_equal(ctx.probe_unpack(8, np.concatenate(packed)), whole)
+    cam = camera_from_scene(scene); cam["aperture"] = 0.0
+    o = oracle_mod.Oracle(pt.StagedScene())
+    ocam = oracle_mod.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+    ref, _ = o.render(ocam, W, H, Dp, 0, spp, 8, rank=666, world=1999, want_rgb8=False)
+    m = D.tile_owner_mask(W, H, 666, 1999)[::-1]
+    assert ref[m].any() and np.array_equal(whole[m], ref[m])
     pt.close()
 
 

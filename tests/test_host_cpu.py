@@ -272,6 +272,19 @@ def _write_png(path, a):
                            + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
+def test_truncated_radiance_hdr_does_not_hang(tmp_path):
+    """A run-length coded .hdr cut off inside a scanline: past the end every byte reads as 0, i.e. a zero-length run
+    that never advances - the reference's stb_image spins forever there; Image::Load here gives up (texture samples as 0)."""
+    from pbrpathtracer_amd import pathtracer as P
+    head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 8\n"
+    row = bytes([2, 2, 0, 8]) + b"".join(bytes([128 + 8, 100 + k]) for k in range(4))     # four runs of 8
+    good = str(tmp_path / "ok.hdr"); open(good, "wb").write(head + row + row)
+    assert P.image_load(good) is not None
+    for cut in (len(head) + 4, len(head) + 7, len(head) + len(row) + 5):
+        bad = str(tmp_path / f"cut{cut}.hdr"); open(bad, "wb").write((head + row + row)[:cut])
+        assert P.image_load(bad) is None, cut
+
+
 def test_large_textures_reduce_like_stb_image_resize(tmp_path):
     """Image::Load on a file with a side > 1024 (image.cpp:47-60): the reference reduces it with
     stbir_resize_uint8 (stb_image_resize v0.97, default Mitchell downsampling, clamped edges).  The
