@@ -97,8 +97,10 @@ typedef struct ptk_ctx ptk_ctx;
 int  ptk_create(ptk_ctx** out, int device_ordinal);
 void ptk_destroy(ptk_ctx* ctx);
 
-/* replaces BuildBVH (pathtracer.cpp:260-274, mesh.cpp:169-211): stages the scene, builds the
- * device BVH (own builder; closest hit is tree-independent) and uploads everything to HBM */
+/* replaces BuildBVH (pathtracer.cpp:260-274, mesh.cpp:169-211): stages the scene, builds the BVH (own builders; closest
+ * hit is tree-independent) and leaves everything resident in HBM.  Scenes of >= 4096 triangles are built ON THE GPU - binned
+ * SAH level by level, collapse to the 4-wide quantised nodes, record packing (csrc/bvh_device.hip); smaller ones, and any
+ * scene whose device-built tree would not fit the traversal stack, by the host builder (option "device_build" = 0 forces it) */
 int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene);
 
 /* SetMaterial after BuildBVH (pathtracer.cpp:243-258): the reference's triangles point into the loaded materials, so an
@@ -201,7 +203,8 @@ int ptk_probe_unpack(ptk_ctx* ctx, int world, const float* host_packed /* all ra
  * (cost of the shading / camera-ray block relative to one BVH walk step; defaults: shading 200 for
  * trees of depth <= 8 else 40 (0 = this automatic choice), camera rays 16); "tri_threshold" = the
  * triangle arm of the BVH walk runs once the lanes holding a leaf reach this many eighths of the lanes
- * that can still walk (default 4; 0 = every iteration); "primary_cache" = 0/1, reuse the camera ray's closest
+ * that can still walk (default 4; 0 = every iteration); "device_build" = 0/1 (default 1): build the BVH of scenes of >= 4096 triangles on the GPU;
+ * "primary_cache" = 0/1, reuse the camera ray's closest
  * hit across samples when the camera is a pinhole and the scene has no opacity texture (default 1). */
 int ptk_set_option(ptk_ctx* ctx, const char* name, double value);
 
@@ -213,7 +216,13 @@ int ptk_last_kernel_ms(ptk_ctx* ctx, float* trace_ms, float* accumulate_ms);
 int ptk_collect_stats(ptk_ctx* ctx, uint32_t first_sample, uint32_t spp_count, uint64_t seed, ptk_stats* out);
 int ptk_bvh_info(ptk_ctx* ctx, int32_t* num_nodes, int32_t* depth /* wide nodes on the longest chain */, int32_t* num_leaf_tris);
 /* child boxes per node record (4), bytes per record (64), most stack entries a traversal of this tree can need */
+/* host milliseconds of the last ptk_upload_scene: [0] BVH build, [1] record packing, [2] device allocation + copies, [3] total */
+int ptk_upload_timing(ptk_ctx* ctx, double* ms4, int* built_on_device /* may be NULL */);
 int ptk_bvh_layout(ptk_ctx* ctx, int32_t* node_width, int32_t* node_bytes, int32_t* stack_need);
+
+/* the tree as it lies in HBM, for structural tests of the builders: num_nodes x 16 floats (ptk_device.h BVH4 record) and,
+ * for every triangle record in leaf order, the scene triangle it holds */
+int ptk_download_bvh(ptk_ctx* ctx, float* nodes16, int32_t* leaf_order);
 
 /* probes used by the parity tests (same semantics as the kernels' device functions) */
 int ptk_probe_hits(ptk_ctx* ctx, int n, const float* ro, const float* rd, int32_t* tri, float* tuv);

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -16,6 +17,7 @@
 #include <vector>
 
 #include "bvh_build.h"
+#include "bvh_device.h"
 #include "ptk_device.h"
 
 using namespace ptk;
@@ -33,6 +35,7 @@ struct ptk_ctx {
     uint32_t* d_texels = nullptr;
     int num_nodes = 0, num_tris = 0, num_lights = 0, bvh_depth = 0, bvh_stack = 0, num_leaf_tris = 0;
     bool have_scene = false;
+    double upload_ms[4] = { 0, 0, 0, 0 };       // last ptk_upload_scene: BVH build, record packing, device copies, total
     // host copies kept for ptk_update_materials: what was uploaded, the texture index map, the light records
     std::vector<ptk_material> h_materials;
     std::vector<int32_t> h_texmap, h_light_material;
@@ -95,6 +98,8 @@ struct ptk_ctx {
     int opt_generations = 0;                     // 0 automatic: 1 on a single GPU, 2 when the frame is split over ranks
     int opt_persistent = -1;                     // -1 automatic (by launch size), 0 one item per wave, 1 persistent waves
     int opt_max_batch = 1;                       // slots a persistent wave pops from its queue at once; > 1 measured slower everywhere
+    int opt_device_build = 1;                    // scenes of >= 4096 triangles: BVH built and records packed on the GPU (bvh_device.hip)
+    bool built_on_device = false;
     int opt_tri_thr = 4;                         // triangle arm of the walk runs when queued lanes >= tri_thr/8 x walking lanes
     int opt_shade_thr = 0, opt_gen_thr = 16;     // scheduling lambdas in eighths, see trace_kernel; 0 = by tree depth
     size_t opt_pass_bytes = (size_t)4 << 30;     // sample-buffer budget per pass
@@ -529,11 +534,34 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
 
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    // BVH: on the device for scenes large enough to matter (replaces BVHNode::Construct, mesh.cpp:169-211), else - or when
+    // the device build cannot meet the traversal-stack bound - by the host builder, which always can
     BuiltBvh bvh;
-    if (!build_bvh(s->verts, n, PTK_MAX_BVH_DEPTH, 4, bvh))
-        return fail(c, PTK_ERR_LIMIT, "BVH exceeds the kernel's depth / index limits");
-    if (bvh.stack_need > PTK_MAX_BVH_DEPTH) return fail(c, PTK_ERR_LIMIT, "BVH needs more entries than the LDS traversal stack holds");
+    DeviceBvh dbvh;
+    bool on_device = false;
+    float* d_verts = nullptr;
+    struct TmpFree { std::vector<void*> p; ~TmpFree() { for (void* q : p) if (q) (void)hipFree(q); } } tmp;
+    if (c->opt_device_build && n >= 4096)
+    {
+        HIPCHK(c, hipMalloc(&d_verts, (size_t)n * 9 * sizeof(float)));
+        tmp.p.push_back(d_verts);
+        HIPCHK(c, hipMemcpyAsync(d_verts, s->verts, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        std::string derr;
+        on_device = build_bvh_device(d_verts, n, PTK_MAX_BVH_DEPTH, 4, c->stream, dbvh, &derr);
+        if (on_device && dbvh.stack_need > PTK_MAX_BVH_DEPTH) { (void)hipFree(dbvh.d_nodes); (void)hipFree(dbvh.d_order); on_device = false; }
+    }
+    if (!on_device)
+    {
+        if (!build_bvh(s->verts, n, PTK_MAX_BVH_DEPTH, 4, bvh))
+            return fail(c, PTK_ERR_LIMIT, "BVH exceeds the kernel's depth / index limits");
+        if (bvh.stack_need > PTK_MAX_BVH_DEPTH) return fail(c, PTK_ERR_LIMIT, "BVH needs more entries than the LDS traversal stack holds");
+    }
+    struct DevBvhGuard { DeviceBvh& d; bool armed; ~DevBvhGuard() { if (armed) { (void)hipFree(d.d_nodes); (void)hipFree(d.d_order); } } } dguard{ dbvh, on_device };
 
+    c->upload_ms[0] = ms_since(t_begin);
+    const auto t_pack = std::chrono::steady_clock::now();
     // a texture with zero extent behaves like a missing image: tex2D returns 0 (image.cpp:65-66);
     // staged as a 1x1 black texel so the kernel needs no special case
     std::vector<int32_t> texmap(s->num_textures, -1);
@@ -561,9 +589,10 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     std::vector<float> mats((size_t)s->num_materials * MAT_F4 * 4, 0.0f);
     for (int32_t i = 0; i < s->num_materials; i++) pack_material(s->materials[i], texmap, mats.data() + (size_t)i * MAT_F4 * 4);
 
-    std::vector<float> tris((size_t)n * TRI_F4 * 4, 0.0f);
+    std::vector<float> tris, shade;
     c->num_leaf_tris = n;
-    for (int32_t k = 0; k < n; k++)
+    if (!on_device) tris.assign((size_t)n * TRI_F4 * 4, 0.0f);
+    for (int32_t k = 0; k < n && !on_device; k++)
     {
         int32_t i = bvh.order[k];
         const float* v = s->verts + (size_t)i * 9;
@@ -576,8 +605,8 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
         q[10] = as_float(ot >= 0 ? texmap[ot] : -1);
         q[11] = 0.0f;
     }
-    std::vector<float> shade((size_t)n * SHADE_F4 * 4, 0.0f);
-    for (int32_t i = 0; i < n; i++)
+    if (!on_device) shade.assign((size_t)n * SHADE_F4 * 4, 0.0f);
+    for (int32_t i = 0; i < n && !on_device; i++)
     {
         const float* nn = s->normals + (size_t)i * 9;
         const float* uv = s->uvs + (size_t)i * 6;
@@ -605,6 +634,8 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
         q[12] = m.emissive[2] * m.emissive_intensity;
     }
 
+    c->upload_ms[1] = ms_since(t_pack);
+    const auto t_copy = std::chrono::steady_clock::now();
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_mats); dfree(c->d_lights);
     dfree(c->d_texinfo); dfree(c->d_texels);
     c->have_scene = false;
@@ -615,9 +646,41 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
         if (bytes) return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
         return hipSuccess;
     };
-    HIPCHK(c, up((void**)&c->d_nodes, bvh.nodes.data(), bvh.nodes.size() * 4));
-    HIPCHK(c, up((void**)&c->d_tris, tris.data(), tris.size() * 4));
-    HIPCHK(c, up((void**)&c->d_shade, shade.data(), shade.size() * 4));
+    if (on_device)
+    {
+        // the records are packed on the device from the boundary's flat arrays (one pass each; no host-side copies)
+        float *d_normals = nullptr, *d_uvs = nullptr, *d_tbn = nullptr; uint8_t* d_smooth = nullptr; int32_t *d_material = nullptr, *d_optex = nullptr;
+        std::vector<int32_t> optex(std::max<int32_t>(s->num_materials, 1), -1);
+        for (int32_t i = 0; i < s->num_materials; i++) { const int32_t ot = s->materials[i].tex[5]; optex[i] = ot >= 0 ? texmap[ot] : -1; }
+        auto tup = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+            hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+            if (e != hipSuccess) return e;
+            tmp.p.push_back(*dst);
+            return bytes ? hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+        };
+        HIPCHK(c, tup((void**)&d_normals, s->normals, (size_t)n * 9 * sizeof(float)));
+        HIPCHK(c, tup((void**)&d_uvs, s->uvs, (size_t)n * 6 * sizeof(float)));
+        HIPCHK(c, tup((void**)&d_tbn, s->tbn, (size_t)n * 9 * sizeof(float)));
+        HIPCHK(c, tup((void**)&d_smooth, s->smoothing, (size_t)n));
+        HIPCHK(c, tup((void**)&d_material, s->material, (size_t)n * sizeof(int32_t)));
+        HIPCHK(c, tup((void**)&d_optex, optex.data(), optex.size() * sizeof(int32_t)));
+        HIPCHK(c, hipMalloc(&c->d_tris, (size_t)n * TRI_F4 * sizeof(float4)));
+        HIPCHK(c, hipMalloc(&c->d_shade, (size_t)n * SHADE_F4 * sizeof(float4)));
+        launch_pack_tris(d_verts, dbvh.d_order, d_material, d_optex, c->d_tris, n, c->stream);
+        launch_pack_shade(d_normals, d_uvs, d_tbn, d_smooth, d_material, c->d_shade, n, c->stream);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->d_nodes = dbvh.d_nodes; dguard.armed = false;
+        (void)hipFree(dbvh.d_order); dbvh.d_order = nullptr;
+        bvh.num_nodes = dbvh.num_nodes; bvh.depth = dbvh.depth; bvh.stack_need = dbvh.stack_need;
+    }
+    else
+    {
+        HIPCHK(c, up((void**)&c->d_nodes, bvh.nodes.data(), bvh.nodes.size() * 4));
+        HIPCHK(c, up((void**)&c->d_tris, tris.data(), tris.size() * 4));
+        HIPCHK(c, up((void**)&c->d_shade, shade.data(), shade.size() * 4));
+    }
+    c->built_on_device = on_device;
     HIPCHK(c, up((void**)&c->d_mats, mats.data(), mats.size() * 4));
     HIPCHK(c, up((void**)&c->d_lights, lights.data(), lights.size() * 4));
     HIPCHK(c, up((void**)&c->d_texinfo, texinfo.data(), texinfo.size() * sizeof(int4)));
@@ -626,6 +689,7 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     c->scene_has_opacity = false;
     for (int32_t i = 0; i < n; i++)
         if (s->materials[s->material[i]].tex[5] >= 0) { c->scene_has_opacity = true; break; }
+    c->upload_ms[2] = ms_since(t_copy); c->upload_ms[3] = ms_since(t_begin);
     c->h_materials.assign(s->materials, s->materials + s->num_materials);
     c->h_texmap = texmap;
     c->h_lights = lights;
@@ -1168,6 +1232,11 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
         c->opt_flat = value != 0.0;
         return PTK_OK;
     }
+    if (!std::strcmp(name, "device_build"))
+    {
+        c->opt_device_build = value != 0.0;
+        return PTK_OK;
+    }
     if (!std::strcmp(name, "primary_cache"))
     {
         c->opt_primary_cache = value != 0.0;
@@ -1192,12 +1261,36 @@ int ptk_bvh_info(ptk_ctx* c, int32_t* num_nodes, int32_t* depth, int32_t* num_le
     return PTK_OK;
 }
 
+int ptk_upload_timing(ptk_ctx* c, double* ms4, int* built_on_device)
+{
+    if (!c || !ms4) return PTK_ERR_BAD_ARG;
+    for (int k = 0; k < 4; k++) ms4[k] = c->upload_ms[k];
+    if (built_on_device) *built_on_device = c->built_on_device ? 1 : 0;
+    return PTK_OK;
+}
+
 int ptk_bvh_layout(ptk_ctx* c, int32_t* node_width, int32_t* node_bytes, int32_t* stack_need)
 {
     if (!c) return PTK_ERR_BAD_ARG;
     if (node_width) *node_width = 4;
     if (node_bytes) *node_bytes = NODE_F4 * 16;
     if (stack_need) *stack_need = c->bvh_stack;
+    return PTK_OK;
+}
+
+int ptk_download_bvh(ptk_ctx* c, float* nodes16, int32_t* leaf_order)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    if (!c->have_scene) return fail(c, PTK_ERR_BAD_ARG, "ptk_upload_scene has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (nodes16 && c->num_nodes > 0) HIPCHK(c, hipMemcpy(nodes16, c->d_nodes, (size_t)c->num_nodes * NODE_F4 * sizeof(float4), hipMemcpyDeviceToHost));
+    if (leaf_order && c->num_tris > 0)
+    {
+        std::vector<float> t((size_t)c->num_tris * TRI_F4 * 4);
+        HIPCHK(c, hipMemcpy(t.data(), c->d_tris, t.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int32_t k = 0; k < c->num_tris; k++) std::memcpy(&leaf_order[k], &t[(size_t)k * TRI_F4 * 4 + 9], 4);
+    }
     return PTK_OK;
 }
 

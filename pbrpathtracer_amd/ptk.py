@@ -63,7 +63,7 @@ SYMBOLS = [
     "ptk_request_exit", "ptk_synchronize", "ptk_last_error", "ptk_accum_device_ptr", "ptk_rgb8_device_ptr",
     "ptk_bind_accum", "ptk_set_stream", "ptk_gather_accum", "ptk_set_option", "ptk_last_render_ms",
     "ptk_last_kernel_ms", "ptk_collect_stats",
-    "ptk_bvh_info", "ptk_bvh_layout", "ptk_probe_hits", "ptk_probe_primary_dirs", "ptk_host_alloc", "ptk_host_free",
+    "ptk_bvh_info", "ptk_bvh_layout", "ptk_upload_timing", "ptk_download_bvh", "ptk_probe_hits", "ptk_probe_primary_dirs", "ptk_host_alloc", "ptk_host_free",
     "ptk_packed_floats", "ptk_packed_layout", "ptk_comm_unique_id", "ptk_comm_init", "ptk_comm_destroy",
     "ptk_gather_wait", "ptk_read_gathered", "ptk_gathered_device_ptr", "ptk_probe_pack", "ptk_probe_unpack",
 ]
@@ -119,6 +119,8 @@ def load() -> C.CDLL:
     L.ptk_collect_stats.argtypes = [vp, u32, u32, u64, C.POINTER(Stats)]
     L.ptk_bvh_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ptk_bvh_layout.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.ptk_download_bvh.argtypes = [vp, vp, vp]
+    L.ptk_upload_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.ptk_probe_hits.argtypes = [vp, i32, vp, vp, vp, vp]
     L.ptk_probe_primary_dirs.argtypes = [vp, vp]
     _lib = L
@@ -262,6 +264,19 @@ class Context:
         w = C.c_int32(); b = C.c_int32(); s = C.c_int32()
         self._chk(self.L.ptk_bvh_layout(self.h, C.byref(w), C.byref(b), C.byref(s)), "ptk_bvh_layout")
         return w.value, b.value, s.value
+
+    def download_bvh(self):
+        n_nodes, _, n_tris = self.bvh_info()
+        nodes = np.zeros((n_nodes, 16), np.float32); order = np.zeros(n_tris, np.int32)
+        self._chk(self.L.ptk_download_bvh(self.h, nodes.ctypes.data, order.ctypes.data), "ptk_download_bvh")
+        return nodes, order
+
+    def upload_timing(self):
+        t = (C.c_double * 4)(); dev = C.c_int(0)
+        self._chk(self.L.ptk_upload_timing(self.h, t, C.byref(dev)), "ptk_upload_timing")
+        d = dict(zip(("bvh_ms", "pack_ms", "copy_ms", "total_ms"), [round(x, 2) for x in t]))
+        d["built_on_device"] = bool(dev.value)
+        return d
 
     def node_width(self) -> int:
         return self.bvh_layout()[0]
