@@ -1,8 +1,10 @@
 // Internal host-side scene staging shared by pathtracer.cpp / scene_io.cpp / ptk_host.cpp.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pathtracer.h"
@@ -30,6 +32,20 @@ struct ObjData {
     std::vector<float> positions, normals, texcoords;
     std::vector<ObjShape> shapes;
 };
+
+// host-side data parallelism for scene ingest (a million triangles: parsing, staging, flattening)
+inline size_t host_threads() { const unsigned h = std::thread::hardware_concurrency(); return std::max<size_t>(1, std::min<size_t>(h ? h : 1, 32)); }
+// f(k) for k in [0, n), spread over the host's cores (one contiguous block of indices per thread)
+template <class F>
+void parallel_for(size_t n, F f, size_t min_per_thread = 1)
+{
+    const size_t t = std::max<size_t>(1, std::min<size_t>(host_threads(), n / std::max<size_t>(1, min_per_thread)));
+    if (t <= 1) { for (size_t k = 0; k < n; k++) f(k); return; }
+    std::vector<std::thread> pool;
+    for (size_t w = 0; w < t; w++)
+        pool.emplace_back([=, &f] { const size_t a = n * w / t, b = n * (w + 1) / t; for (size_t k = a; k < b; k++) f(k); });
+    for (auto& th : pool) th.join();
+}
 
 bool load_obj(const std::string& file, ObjData& out);
 void triangle_init(StagedTriangle& t);

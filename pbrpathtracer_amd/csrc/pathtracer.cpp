@@ -9,6 +9,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <thread>
 
 #include "host_scene.h"
 #include "ptk.h"
@@ -56,102 +57,213 @@ void triangle_init(StagedTriangle& t)
 // Replaces tinyobj::LoadObj as used by PathTracer::LoadObject (pathtracer.cpp:43-47): v / vt / vn / f
 // (negative indices, v, v/vt, v//vn, v/vt/vn; polygons fan-triangulated), one shape per `o` or `g`
 // statement that is followed by faces (tiny_obj_loader.h:2820-2900), per-face smoothing group from `s`.
-bool load_obj(const std::string& file, ObjData& out)
+// Large files (a million triangles is 60 MB of text) are parsed by all cores: the file is cut at line ends into one chunk
+// per thread; a first pass counts the v / vn / vt statements of every chunk (relative face indices and the output offsets
+// need the counts before a line), a second parses numbers and faces in place; shapes and smoothing groups, which are
+// sequential state, are stitched from per-chunk fragments afterwards.  Statement semantics are those of the line-by-line
+// reader this replaces (and of the fixtures recorded from the reference's tinyobjloader).
+namespace {
+
+struct ObjFragment {
+    bool new_shape = false;               // begins with an `o` / `g` statement
+    std::string name;
+    std::vector<ObjIndex> indices;
+    std::vector<unsigned> smoothing;      // kUnknownSmoothing until the chunk's first `s`: the value flows in from before
+};
+constexpr unsigned kUnknownSmoothing = 0xffffffffu;
+
+struct ObjChunk {
+    const char* begin = nullptr; const char* end = nullptr;
+    size_t nv = 0, nvn = 0, nvt = 0;      // statements in this chunk
+    size_t v0 = 0, vn0 = 0, vt0 = 0;      // ... before it
+    std::vector<ObjFragment> frags;
+    bool has_s = false; unsigned last_s = 0;
+};
+
+inline const char* skip_blank(const char* p, const char* e) { while (p < e && (*p == ' ' || *p == '\t')) p++; return p; }
+inline const char* line_end(const char* p, const char* e) { while (p < e && *p != '\n') p++; return p; }
+
+// up to `count` floats of one line (sscanf("%f %f %f") semantics: missing ones stay 0)
+inline void parse_floats(const char* p, const char* e, float* out, int count)
 {
-    std::ifstream in(file);
-    if (!in) return false;
-    out = ObjData();
-    ObjShape shape;
-    unsigned smoothing = 0;
-    std::string line;
-    auto flush = [&]() {
-        if (!shape.indices.empty()) out.shapes.push_back(shape);
-        shape = ObjShape();
-    };
-    auto fix = [](int idx, size_t n) -> int {
-        if (idx > 0) return idx - 1;
-        if (idx < 0) return (int)n + idx;
+    for (int k = 0; k < count; k++)
+    {
+        p = skip_blank(p, e);
+        if (p >= e || *p == '\r') return;
+        char* q = nullptr;
+        const float v = std::strtof(p, &q);
+        if (q == p) return;
+        out[k] = v; p = q;
+    }
+}
+
+void count_chunk(ObjChunk& c)
+{
+    for (const char* p = c.begin; p < c.end;)
+    {
+        const char* e = line_end(p, c.end);
+        const char* q = skip_blank(p, e);
+        if (q + 1 < e && q[0] == 'v')
+        {
+            if (q[1] == ' ' || q[1] == '\t') c.nv++;
+            else if (q[1] == 'n' && q + 2 < e && (q[2] == ' ' || q[2] == '\t')) c.nvn++;
+            else if (q[1] == 't' && q + 2 < e && (q[2] == ' ' || q[2] == '\t')) c.nvt++;
+        }
+        p = e + 1;
+    }
+}
+
+void parse_chunk(ObjChunk& c, float* positions, float* normals, float* texcoords)
+{
+    size_t nv = c.v0, nvn = c.vn0, nvt = c.vt0;
+    c.frags.emplace_back();
+    bool s_known = false; unsigned smoothing = kUnknownSmoothing;
+    auto fix = [](long idx, size_t n) -> int {
+        if (idx > 0) return (int)idx - 1;
+        if (idx < 0) return (int)n + (int)idx;
         return -1;
     };
-    while (std::getline(in, line))
+    std::vector<ObjIndex> face;
+    for (const char* p0 = c.begin; p0 < c.end;)
     {
-        const char* p = line.c_str();
-        while (*p == ' ' || *p == '\t') p++;
-        if (*p == '\0' || *p == '#' || *p == '\r') continue;
-        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t'))
+        const char* e = line_end(p0, c.end);
+        const char* p = skip_blank(p0, e);
+        p0 = e + 1;
+        if (p >= e || *p == '#' || *p == '\r') continue;
+        const char c1 = p + 1 < e ? p[1] : '\0', c2 = p + 2 < e ? p[2] : '\0';
+        if (p[0] == 'v' && (c1 == ' ' || c1 == '\t'))
         {
-            float x = 0, y = 0, z = 0;
-            std::sscanf(p + 2, "%f %f %f", &x, &y, &z);
-            out.positions.push_back(x); out.positions.push_back(y); out.positions.push_back(z);
+            float v[3] = { 0, 0, 0 };
+            parse_floats(p + 2, e, v, 3);
+            positions[nv * 3] = v[0]; positions[nv * 3 + 1] = v[1]; positions[nv * 3 + 2] = v[2]; nv++;
         }
-        else if (p[0] == 'v' && p[1] == 'n' && (p[2] == ' ' || p[2] == '\t'))
+        else if (p[0] == 'v' && c1 == 'n' && (c2 == ' ' || c2 == '\t'))
         {
-            float x = 0, y = 0, z = 0;
-            std::sscanf(p + 3, "%f %f %f", &x, &y, &z);
-            out.normals.push_back(x); out.normals.push_back(y); out.normals.push_back(z);
+            float v[3] = { 0, 0, 0 };
+            parse_floats(p + 3, e, v, 3);
+            normals[nvn * 3] = v[0]; normals[nvn * 3 + 1] = v[1]; normals[nvn * 3 + 2] = v[2]; nvn++;
         }
-        else if (p[0] == 'v' && p[1] == 't' && (p[2] == ' ' || p[2] == '\t'))
+        else if (p[0] == 'v' && c1 == 't' && (c2 == ' ' || c2 == '\t'))
         {
-            float x = 0, y = 0;
-            std::sscanf(p + 3, "%f %f", &x, &y);
-            out.texcoords.push_back(x); out.texcoords.push_back(y);
+            float v[2] = { 0, 0 };
+            parse_floats(p + 3, e, v, 2);
+            texcoords[nvt * 2] = v[0]; texcoords[nvt * 2 + 1] = v[1]; nvt++;
         }
-        else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t'))
+        else if (p[0] == 'f' && (c1 == ' ' || c1 == '\t'))
         {
-            std::vector<ObjIndex> face;
+            face.clear();
             const char* q = p + 2;
-            while (*q)
+            while (q < e)
             {
-                while (*q == ' ' || *q == '\t' || *q == '\r') q++;
-                if (!*q) break;
+                while (q < e && (*q == ' ' || *q == '\t' || *q == '\r')) q++;
+                if (q >= e) break;
                 ObjIndex ix = { -1, -1, -1 };
-                char* end = 0;
+                char* end = nullptr;
                 long v = std::strtol(q, &end, 10);
                 if (end == q) break;
-                ix.v = fix((int)v, out.positions.size() / 3);
+                ix.v = fix(v, nv);
                 q = end;
-                if (*q == '/')
+                if (q < e && *q == '/')
                 {
                     q++;
-                    if (*q != '/')
+                    if (q < e && *q != '/')
                     {
                         long t = std::strtol(q, &end, 10);
-                        if (end != q) { ix.t = fix((int)t, out.texcoords.size() / 2); q = end; }
+                        if (end != q) { ix.t = fix(t, nvt); q = end; }
                     }
-                    if (*q == '/')
+                    if (q < e && *q == '/')
                     {
                         q++;
                         long n = std::strtol(q, &end, 10);
-                        if (end != q) { ix.n = fix((int)n, out.normals.size() / 3); q = end; }
+                        if (end != q) { ix.n = fix(n, nvn); q = end; }
                     }
                 }
                 face.push_back(ix);
             }
+            ObjFragment& f = c.frags.back();
             for (size_t k = 2; k < face.size(); k++)
             {
-                shape.indices.push_back(face[0]); shape.indices.push_back(face[k - 1]); shape.indices.push_back(face[k]);
-                shape.smoothing.push_back(smoothing);
+                f.indices.push_back(face[0]); f.indices.push_back(face[k - 1]); f.indices.push_back(face[k]);
+                f.smoothing.push_back(s_known ? smoothing : kUnknownSmoothing);
             }
         }
-        else if ((p[0] == 'o' || p[0] == 'g') && (p[1] == ' ' || p[1] == '\t' || p[1] == '\0' || p[1] == '\r'))
+        else if ((p[0] == 'o' || p[0] == 'g') && (c1 == ' ' || c1 == '\t' || c1 == '\0' || c1 == '\r'))
         {
-            flush();
-            const char* q = p + 1;
-            while (*q == ' ' || *q == '\t') q++;
-            std::string name(q);
+            const char* q = skip_blank(p + 1, e);
+            std::string name(q, e);
             while (!name.empty() && (name.back() == '\r' || name.back() == ' ' || name.back() == '\t')) name.pop_back();
-            if (p[0] == 'g') { size_t sp = name.find_first_of(" \t"); (void)sp; }
-            shape.name = name;
+            c.frags.emplace_back();
+            c.frags.back().new_shape = true;
+            c.frags.back().name = name;
         }
-        else if (p[0] == 's' && (p[1] == ' ' || p[1] == '\t'))
+        else if (p[0] == 's' && (c1 == ' ' || c1 == '\t'))
         {
-            const char* q = p + 2;
-            while (*q == ' ' || *q == '\t') q++;
-            if (!std::strncmp(q, "off", 3)) smoothing = 0;
-            else { int id = std::atoi(q); smoothing = id < 0 ? 0u : (unsigned)id; }
+            const char* q = skip_blank(p + 2, e);
+            if (e - q >= 3 && !std::strncmp(q, "off", 3)) smoothing = 0;
+            else { int id = (int)std::strtol(q, nullptr, 10); smoothing = id < 0 ? 0u : (unsigned)id; }
+            s_known = true; c.has_s = true; c.last_s = smoothing;
         }
     }
-    flush();
+}
+
+}  // namespace
+
+bool load_obj(const std::string& file, ObjData& out)
+{
+    out = ObjData();
+    std::string buf;
+    {
+        FILE* f = std::fopen(file.c_str(), "rb");
+        if (!f) return false;
+        std::fseek(f, 0, SEEK_END);
+        const long size = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        if (size < 0) { std::fclose(f); return false; }
+        buf.resize((size_t)size);
+        const size_t got = size ? std::fread(&buf[0], 1, (size_t)size, f) : 0;
+        std::fclose(f);
+        buf.resize(got);
+    }
+    const char* base = buf.c_str();                        // NUL-terminated: strtof / strtol never run past the end
+    const size_t size = buf.size();
+    const int nchunks = (int)std::max<size_t>(1, std::min<size_t>(host_threads(), size / (256 * 1024)));
+    std::vector<ObjChunk> chunks(nchunks);
+    {
+        const char* p = base;
+        for (int k = 0; k < nchunks; k++)
+        {
+            chunks[k].begin = p;
+            const char* e = k + 1 == nchunks ? base + size : line_end(base + (size_t)(k + 1) * size / nchunks, base + size);
+            if (e < base + size) e++;                      // past the newline
+            if (e < p) e = p;
+            chunks[k].end = e; p = e;
+        }
+    }
+    parallel_for(nchunks, [&](size_t k) { count_chunk(chunks[k]); });
+    size_t nv = 0, nvn = 0, nvt = 0;
+    for (ObjChunk& c : chunks) { c.v0 = nv; c.vn0 = nvn; c.vt0 = nvt; nv += c.nv; nvn += c.nvn; nvt += c.nvt; }
+    out.positions.resize(nv * 3); out.normals.resize(nvn * 3); out.texcoords.resize(nvt * 2);
+    parallel_for(nchunks, [&](size_t k) { parse_chunk(chunks[k], out.positions.data(), out.normals.data(), out.texcoords.data()); });
+    // stitch: shapes begin at `o` / `g` statements that are followed by faces; the smoothing group carries across chunks
+    ObjShape shape;
+    unsigned smoothing = 0;
+    for (ObjChunk& c : chunks)
+    {
+        for (ObjFragment& f : c.frags)
+        {
+            if (f.new_shape)
+            {
+                if (!shape.indices.empty()) out.shapes.push_back(std::move(shape));
+                shape = ObjShape();
+                shape.name = f.name;
+            }
+            for (unsigned& sm : f.smoothing) { if (sm != kUnknownSmoothing) break; sm = smoothing; }
+            shape.indices.insert(shape.indices.end(), f.indices.begin(), f.indices.end());
+            shape.smoothing.insert(shape.smoothing.end(), f.smoothing.begin(), f.smoothing.end());
+        }
+        if (c.has_s) smoothing = c.last_s;
+    }
+    if (!shape.indices.empty()) out.shapes.push_back(std::move(shape));
     return true;
 }
 
@@ -247,8 +359,15 @@ void PathTracer::LoadObject(const std::string& file, const glm::mat4& model)
     {
         object.elements.push_back(PathTracerLoader::Element(obj.shapes[i].name));
         const ObjShape& sh = obj.shapes[i];
-        for (size_t j = 0; j + 2 < sh.indices.size() + 0 && j / 3 < sh.smoothing.size(); j += 3)
-        {
+        const size_t ntri = std::min(sh.indices.size() / 3, sh.smoothing.size());
+        const size_t first = m->triangles.size();
+        m->triangles.resize(first + ntri);
+        std::vector<uint8_t> okv(ntri, 1);
+        const int objectId = (int)m->objects.size();
+        StagedTriangle* dst = m->triangles.data() + first;
+        // every triangle is staged independently (x-negation, model transform, v-flip, Triangle::Init): all cores
+        parallel_for(ntri, [&](size_t tj) {
+            const size_t j = tj * 3;
             StagedTriangle t;
             std::memset(&t, 0, sizeof(t));
             bool ok = true;
@@ -269,13 +388,18 @@ void PathTracer::LoadObject(const std::string& file, const glm::mat4& model)
                     t.uv[k][1] = 1.0f - obj.texcoords[2 * ix.t + 1];                                                    // v-flip (:87-88)
                 }
             }
-            if (!ok) continue;
+            if (!ok) { okv[tj] = 0; return; }
             triangle_init(t);
-            t.smoothing = sh.smoothing[j / 3] != 0;            // :131-135
-            t.objectId = (int)m->objects.size();
+            t.smoothing = sh.smoothing[tj] != 0;               // :131-135
+            t.objectId = objectId;
             t.elementId = (int)i;
-            m->triangles.push_back(t);
-        }
+            dst[tj] = t;
+        }, 4096);
+        // faces that name a vertex the file does not have are dropped, the rest keep their order
+        size_t kept = 0;
+        for (size_t tj = 0; tj < ntri; tj++)
+            if (okv[tj]) { if (kept != tj) dst[kept] = dst[tj]; kept++; }
+        m->triangles.resize(first + kept);
     }
     m->objects.push_back(object);
     m->scene_uploaded = false;

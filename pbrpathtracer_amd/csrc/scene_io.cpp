@@ -71,25 +71,29 @@ void flatten_scene(const std::vector<StagedTriangle>& tris, const std::vector<Pa
             out.materials.push_back(pm);
         }
     }
-    size_t n = tris.size();
-    out.verts.reserve(n * 9); out.normals.reserve(n * 9); out.uvs.reserve(n * 6); out.tbn.reserve(n * 9);
-    for (size_t i = 0; i < n; i++)
+    const size_t n = tris.size();
+    out.verts.resize(n * 9); out.normals.resize(n * 9); out.uvs.resize(n * 6); out.tbn.resize(n * 9);
+    out.smoothing.resize(n); out.material.resize(n);
+    // which materials emit: glm::length(emissive) >= EPS, constant colour only (pathtracer.cpp:271-272)
+    std::vector<uint8_t> emits(out.materials.size(), 0);
+    for (size_t k = 0; k < out.materials.size(); k++)
     {
-        const StagedTriangle& t = tris[i];
-        for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) out.verts.push_back(t.v[k][a]);
-        for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) out.normals.push_back(t.n[k][a]);
-        for (int k = 0; k < 3; k++) for (int a = 0; a < 2; a++) out.uvs.push_back(t.uv[k][a]);
-        for (int a = 0; a < 3; a++) out.tbn.push_back(t.normal[a]);
-        for (int a = 0; a < 3; a++) out.tbn.push_back(t.tangent[a]);
-        for (int a = 0; a < 3; a++) out.tbn.push_back(t.bitangent[a]);
-        out.smoothing.push_back(t.smoothing ? 1 : 0);
-        int mi = base[t.objectId] + t.elementId;
-        out.material.push_back(mi);
-        // light list: glm::length(emissive) >= EPS, constant colour only (pathtracer.cpp:271-272)
-        const ptk_material& pm = out.materials[mi];
-        float sqr = pm.emissive[0] * pm.emissive[0] + pm.emissive[1] * pm.emissive[1] + pm.emissive[2] * pm.emissive[2];
-        if (std::sqrt(sqr) >= EPS) out.lights.push_back((int32_t)i);
+        const ptk_material& pm = out.materials[k];
+        const float sqr = pm.emissive[0] * pm.emissive[0] + pm.emissive[1] * pm.emissive[1] + pm.emissive[2] * pm.emissive[2];
+        emits[k] = std::sqrt(sqr) >= EPS ? 1 : 0;
     }
+    parallel_for(n, [&](size_t i) {
+        const StagedTriangle& t = tris[i];
+        float* v = &out.verts[i * 9]; float* nn = &out.normals[i * 9]; float* uv = &out.uvs[i * 6]; float* tb = &out.tbn[i * 9];
+        for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { v[k * 3 + a] = t.v[k][a]; nn[k * 3 + a] = t.n[k][a]; }
+        for (int k = 0; k < 3; k++) for (int a = 0; a < 2; a++) uv[k * 2 + a] = t.uv[k][a];
+        for (int a = 0; a < 3; a++) { tb[a] = t.normal[a]; tb[3 + a] = t.tangent[a]; tb[6 + a] = t.bitangent[a]; }
+        out.smoothing[i] = t.smoothing ? 1 : 0;
+        out.material[i] = base[t.objectId] + t.elementId;
+    }, 16384);
+    // the light list, in triangle order (mLights, pathtracer.cpp:267-273)
+    for (size_t i = 0; i < n; i++)
+        if (emits[out.material[i]]) out.lights.push_back((int32_t)i);
 }
 
 // ---- glm 0.9.3.1 matrix_transform (gtc/matrix_transform.inl:31-95), degrees -------------------------------
