@@ -520,6 +520,10 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
             return fail(c, PTK_ERR_BAD_ARG, "triangle material index out of range");
     for (int32_t i = 0; i < s->num_lights; i++)
         if (s->lights[i] < 0 || s->lights[i] >= n) return fail(c, PTK_ERR_BAD_ARG, "light triangle index out of range");
+    // the kernels' exact short reciprocal (ptk_kernels.hip rcp_ieee) covers determinants and lengths up to 2^126: coordinates
+    // must stay below 2^61 in magnitude (the reference's own float arithmetic is long meaningless out there)
+    for (size_t i = 0; i < (size_t)n * 9; i++)
+        if (!(std::fabs(s->verts[i]) < 2.305843e18f)) return fail(c, PTK_ERR_LIMIT, "vertex coordinate is not finite or exceeds 2^61");
     for (int32_t i = 0; i < s->num_textures; i++)
     {
         const ptk_texture& t = s->textures[i];

@@ -72,10 +72,38 @@ __device__ __forceinline__ v3 cross(v3 x, v3 y)
 {
     return V(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
 }
+// 1.0f / a, BIT FOR BIT the IEEE-754 round-to-nearest quotient the oracle and the reference compute, for every float with
+// 2^-126 <= |a| <= 2^126: v_rcp_f32 (1 ulp) and one Newton step with an exact residual.  Proven by enumeration - all 2^32
+// bit patterns on this GPU, tools/microbench/exact_math.hip, profiles/r02/exact_math.json: 0 mismatches in that range - and
+// 13 issue cycles instead of the 43 of the compiler's v_div_scale / v_div_fmas / v_div_fixup expansion (which exists for the
+// denormal ranges).  The range cannot be left by a triangle's determinant or a vector's length while scene coordinates stay
+// below 2^61 in magnitude, which ptk_upload_scene enforces.
+#ifndef PTK_SHORT_RCP
+#define PTK_SHORT_RCP 1
+#endif
+__device__ __forceinline__ float rcp_ieee(float a)
+{
+#if PTK_SHORT_RCP
+    const float y = __builtin_amdgcn_rcpf(a);
+    const float e = __builtin_fmaf(-a, y, 1.0f);
+    return __builtin_fmaf(y, e, y);
+#else
+    return 1.0f / a;
+#endif
+}
+// ... plus IEEE results for zeros, infinities and NaNs (one v_div_fixup_f32): where a zero length can occur
+__device__ __forceinline__ float rcp_ieee_any(float a)
+{
+#if PTK_SHORT_RCP
+    return __builtin_amdgcn_div_fixupf(rcp_ieee(a), a, 1.0f);
+#else
+    return 1.0f / a;
+#endif
+}
 __device__ __forceinline__ v3 normalize(v3 a)
 {
     float sqr = a.x * a.x + a.y * a.y + a.z * a.z;
-    float inv = 1.0f / sqrtf(sqr);
+    float inv = rcp_ieee_any(sqrtf(sqr));
     return muls(a, inv);
 }
 __device__ __forceinline__ v3 reflect(v3 I, v3 N)
@@ -229,7 +257,7 @@ __device__ __forceinline__ bool tri_test(const PT& P, Walk& W, float4 t0, float4
     v3 edge2 = V(t1.z, t1.w, t2.x);
     v3 h = cross(rd, edge2);
     float a = dot(edge1, h);
-    float f = 1.0f / a;
+    float f = rcp_ieee(a);                      // (|a| < EPS, a NaN or infinite: rejected below whatever f is)
     v3 s = sub(ro, v0);
     float u = f * dot(s, h);
     v3 q = cross(s, edge1);
@@ -275,7 +303,7 @@ __device__ __forceinline__ bool tri_test_pair(const PT& P, Walk& W, Walk& WS, co
     // h = cross(rd, edge2)
     const f2 hx = R.dy * e2z - R.dz * e2y, hy = R.dz * e2x - R.dx * e2z, hz = R.dx * e2y - R.dy * e2x;
     const f2 a = hx * e1x + hy * e1y + hz * e1z;                 // dot(edge1, h)
-    const f2 f = { 1.0f / a.x, 1.0f / a.y };
+    const f2 f = { rcp_ieee(a.x), rcp_ieee(a.y) };
     const f2 sx = R.ox - v0x, sy = R.oy - v0y, sz = R.oz - v0z;  // s = ro - v0
     const f2 u = f * (sx * hx + sy * hy + sz * hz);
     // q = cross(s, edge1)
@@ -446,6 +474,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
            IT_LO, IT_HI, IT_G,      // slots [lo, hi) of queue g this wave has popped and not yet used
            IT_REMAIN,               // slots that queue had left after that pop (sizes the next batch)
            IT_TAKEN,                // items this wave has traced so far (against the launch's per-wave quota, if any)
+           IT_NLIVE_MAGIC,          // ceil(2^32 / live pixels): unit / live pixels = mulhi(unit, magic), exact while unit * live pixels < 2^32
            IT_WORDS };
     __shared__ uint32_t lds_item[IT_WORDS];
     if (lane == 0)
@@ -544,7 +573,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
             if ((live_mask >> lane) & 1ull) lds_pixel_of_rank[__popcll(live_mask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
             if (lane == 0)
             {
-                lds_item[IT_NLIVE] = n_live; lds_item[IT_X0] = (uint32_t)x0; lds_item[IT_Y0] = (uint32_t)y0;
+                lds_item[IT_NLIVE] = n_live; lds_item[IT_NLIVE_MAGIC] = (uint32_t)((0x100000000ull + n_live - 1u) / n_live); lds_item[IT_X0] = (uint32_t)x0; lds_item[IT_Y0] = (uint32_t)y0;
                 lds_item[IT_SBEGIN] = s_begin; lds_item[IT_STEAL] = (uint32_t)steal; lds_item[IT_TAKEN] += 1u;
                 lds_item[IT_LO] = (uint32_t)lo; lds_item[IT_HI] = (uint32_t)hi; lds_item[IT_G] = (uint32_t)cur_g; lds_item[IT_REMAIN] = remain;
                 lds_item[IT_OUTBASE] = (uint32_t)item * (uint32_t)chunk * 64u;   // sample s of quadrant pixel q: P.samples[base + s * 64 + q]
@@ -623,7 +652,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 const uint32_t u = next_unit + (uint32_t)__popcll(m_need & ((1ull << lane) - 1ull));
                 if (st == ST_NEED && u < total_units)
                 {
-                    const uint32_t s_in_chunk = u / n_live;
+                    const uint32_t s_in_chunk = n_live == 1u ? u : __umulhi(u, lds_item[IT_NLIVE_MAGIC]);   // = u / n_live without the integer-division expansion
                     const uint32_t q = lds_pixel_of_rank[u - s_in_chunk * n_live];
                     pix = (lds_item[IT_Y0] + (q >> 3)) * (uint32_t)P.width + lds_item[IT_X0] + (q & 7u);
                     sample_abs = lds_item[IT_SBEGIN] + s_in_chunk;
