@@ -30,6 +30,7 @@ struct ptk_ctx {
     std::mutex err_mu;
 
     // scene (device)
+    float4* d_flat_tris = nullptr;      // <= 16 triangles: records in ascending triangle index for the FLAT kernel
     float4 *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_mats = nullptr, *d_lights = nullptr;
     int4* d_texinfo = nullptr;
     uint32_t* d_texels = nullptr;
@@ -230,7 +231,7 @@ bool primary_cacheable(const ptk_ctx* c)
 void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint64_t seed)
 {
     std::memset(&p, 0, sizeof(p));
-    p.nodes = c->d_nodes; p.tris = c->d_tris; p.shade = c->d_shade; p.mats = c->d_mats; p.lights = c->d_lights;
+    p.nodes = c->d_nodes; p.tris = c->d_tris; p.flat_tris = c->d_flat_tris; p.shade = c->d_shade; p.mats = c->d_mats; p.lights = c->d_lights;
     p.texinfo = c->d_texinfo; p.texels = c->d_texels; p.primary = c->d_primary;
     p.primary_hit = nullptr;
     p.samples = c->d_samples;
@@ -244,7 +245,7 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     p.generations = c->opt_generations > 0 ? c->opt_generations : (c->world > 1 ? 2 : 1);
     p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.stats = c->d_stats;
     p.num_nodes = c->num_nodes; p.num_lights = c->num_lights;
-    p.flat_count = (c->opt_flat && c->num_tris <= 16) ? c->num_tris : 0;
+    p.flat_count = (c->opt_flat && c->num_tris <= 16 && c->d_flat_tris) ? c->num_tris : 0;
     p.flat_shade_w = c->opt_flat_shade_w; p.flat_gen_w = c->opt_flat_gen_w;
     p.width = c->width; p.height = c->height; p.max_depth = c->max_depth;
     p.tiles_x = (c->width + PTK_TILE - 1) / PTK_TILE;
@@ -462,6 +463,7 @@ void ptk_destroy(ptk_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_mats); dfree(c->d_lights);
+    dfree(c->d_flat_tris);
     dfree(c->d_texinfo); dfree(c->d_texels); dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_primary_rd); dfree(c->d_accum); dfree(c->d_rgb8);
     dfree(c->d_pixel_rng);
     for (int b = 0; b < 2; b++)
@@ -652,6 +654,7 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     };
     if (on_device)
     {
+        dfree(c->d_flat_tris);
         // the records are packed on the device from the boundary's flat arrays (one pass each; no host-side copies)
         float *d_normals = nullptr, *d_uvs = nullptr, *d_tbn = nullptr; uint8_t* d_smooth = nullptr; int32_t *d_material = nullptr, *d_optex = nullptr;
         std::vector<int32_t> optex(std::max<int32_t>(s->num_materials, 1), -1);
@@ -682,6 +685,14 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     {
         HIPCHK(c, up((void**)&c->d_nodes, bvh.nodes.data(), bvh.nodes.size() * 4));
         HIPCHK(c, up((void**)&c->d_tris, tris.data(), tris.size() * 4));
+        dfree(c->d_flat_tris);
+        if (n > 0 && n <= 16)
+        {
+            std::vector<float> flat((size_t)n * TRI_F4 * 4);
+            for (int32_t k = 0; k < n; k++)             // record of leaf position k holds triangle bvh.order[k]
+                std::memcpy(flat.data() + (size_t)bvh.order[k] * TRI_F4 * 4, tris.data() + (size_t)k * TRI_F4 * 4, TRI_F4 * 16);
+            HIPCHK(c, up((void**)&c->d_flat_tris, flat.data(), flat.size() * 4));
+        }
         HIPCHK(c, up((void**)&c->d_shade, shade.data(), shade.size() * 4));
     }
     c->built_on_device = on_device;

@@ -66,6 +66,7 @@ struct RenderParams {
     int tri_thr;                // triangle arm runs when lanes with a queued triangle >= tri_thr/8 x lanes with a node
     const float4* nodes;
     const float4* tris;
+    const float4* flat_tris;    // scenes of <= 16 triangles: the same records in ascending triangle index (FLAT kernel)
     const float4* shade;
     const float4* mats;
     const float4* lights;
@@ -102,6 +103,7 @@ struct PrimaryParams {
 struct ProbeParams {
     const float4* nodes;
     const float4* tris;
+    const float4* flat_tris;    // scenes of <= 16 triangles: the same records in ascending triangle index (FLAT kernel)
     const float4* shade;
     const float4* mats;
     const int4* texinfo;

@@ -264,7 +264,9 @@ __device__ __forceinline__ bool tri_test(const PT& P, Walk& W, float4 t0, float4
     float v = f * dot(rd, q);
     float t = f * dot(edge2, q);
     int tri = __float_as_int(t2.y);
-    bool ok = !(fabsf(a) < PTK_EPS) & !(u < 0.0f) & !(u > 1.0f) & !(v < 0.0f) & !(u + v > 1.0f) & (t > PTK_EPS);
+    // (the reference also returns on u > 1, pathtracer.cpp:393: implied here - v >= 0 makes fl(u + v) >= u, rounding being
+    // monotone, so u > 1 fails the u + v test, and a NaN u passes both forms alike)
+    bool ok = !(fabsf(a) < PTK_EPS) & !(u < 0.0f) & !(v < 0.0f) & !(u + v > 1.0f) & (t > PTK_EPS);
     ok = ok & ((t < W.best.t) | ((t == W.best.t) & (tri < W.best.tri)));
     int otex = __float_as_int(t2.z);
     if (ok && otex >= 0)
@@ -313,10 +315,12 @@ __device__ __forceinline__ bool tri_test_pair(const PT& P, Walk& W, Walk& WS, co
     const f2 uv = u + v;
     const int tri = __float_as_int(t2.y);
     const int otex = __float_as_int(t2.z);
-    bool okb = !(fabsf(a.x) < PTK_EPS) & !(u.x < 0.0f) & !(u.x > 1.0f) & !(v.x < 0.0f) & !(uv.x > 1.0f) & (t.x > PTK_EPS);
-    bool oks = !(fabsf(a.y) < PTK_EPS) & !(u.y < 0.0f) & !(u.y > 1.0f) & !(v.y < 0.0f) & !(uv.y > 1.0f) & (t.y > PTK_EPS);
-    okb = okb & ((t.x < W.best.t) | ((t.x == W.best.t) & (tri < W.best.tri)));
-    oks = oks & shadow_live & ((t.y < WS.best.t) | ((t.y == WS.best.t) & (tri < WS.best.tri)));
+    bool okb = !(fabsf(a.x) < PTK_EPS) & !(u.x < 0.0f) & !(v.x < 0.0f) & !(uv.x > 1.0f) & (t.x > PTK_EPS);     // (u > 1: implied, see tri_test)
+    bool oks = !(fabsf(a.y) < PTK_EPS) & !(u.y < 0.0f) & !(v.y < 0.0f) & !(uv.y > 1.0f) & (t.y > PTK_EPS);
+    // the flat list is in ascending triangle index, so the tie rule's "equal t and smaller index" can never hold for a
+    // later record: nearer-than-best is the whole rule
+    okb = okb & (t.x < W.best.t);
+    oks = oks & shadow_live & (t.y < WS.best.t);
     if ((okb | oks) && otex >= 0)
     {
         // stochastic opacity, pathtracer.cpp:469-476 (GetUV :533-536); rare: skipped with s_cbranch_execz
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 {
                     typedef float f4v __attribute__((ext_vector_type(4)));
                     typedef const __attribute__((address_space(4))) f4v* cf4;        // constant address space -> s_load
-                    const cf4 ct = (cf4)(uintptr_t)P.tris;
+                    const cf4 ct = (cf4)(uintptr_t)P.flat_tris;            // the scene's triangles in ascending index order
                     // both rays of a diffuse bounce in one pass over the triangles: the shadow ray
                     // (ray number `ray`) and the sampled bounce (`ray + 1`), pathtracer.cpp:638 / :724
                     const bool shadow = WS.occl_tri >= 0;
