@@ -66,6 +66,7 @@ struct ptk_ctx {
 
     std::atomic<int> samples{ 0 };
     std::atomic<uint32_t> exit_req{ 0 };
+    std::atomic<uint32_t> render_gen{ 1 };       // generation of the render in flight: Exit() names it, later renders are not affected
     uint32_t* d_exit = nullptr;
     unsigned long long* d_stats = nullptr;
     unsigned* d_queues = nullptr;                // item queues of trace_kernel's persistent waves
@@ -243,7 +244,7 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     p.max_batch = c->opt_max_batch;
     p.persistent = c->opt_persistent;
     p.generations = c->opt_generations > 0 ? c->opt_generations : (c->world > 1 ? 2 : 1);
-    p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.stats = c->d_stats;
+    p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.exit_gen = c->render_gen.load(); p.stats = c->d_stats;
     p.num_nodes = c->num_nodes; p.num_lights = c->num_lights;
     p.flat_count = (c->opt_flat && c->num_tris <= 16 && c->d_flat_tris) ? c->num_tris : 0;
     p.flat_shade_w = c->opt_flat_shade_w; p.flat_gen_w = c->opt_flat_gen_w;
@@ -809,9 +810,7 @@ int ptk_reset(ptk_ctx* c)
     HIPCHK(c, hipMemsetAsync(accum_ptr(c), 0, px * 3 * sizeof(float), c->stream));     // pathtracer.cpp:745-751
     HIPCHK(c, hipMemsetAsync(c->d_rgb8, 0, px * 3, c->stream));
     c->samples = 0;
-    c->exit_req = 0;
-    HIPCHK(c, hipMemsetAsync(c->d_exit, 0, sizeof(uint32_t), c->stream));
-    c->inputs_dirty = true;                      // the trace streams must see the cleared exit flag
+    c->exit_req = 0;                             // (an earlier Exit() named an earlier render's generation: nothing to clear on the device)
     return PTK_OK;
 }
 
@@ -826,10 +825,11 @@ int ptk_render(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uint64_t s
     c->timed = false;
     if (spp_count == 0) return PTK_OK;
     // RenderFrame() begins with mExit = false (pathtracer.cpp:742): an Exit() only cuts the frame(s) in flight, the next
-    // call renders again.  Stream-ordered, so a render still running keeps seeing the flag it was aborted with.
+    // call renders again.
+    // (an Exit() names the generation of the render it interrupts; this render gets a new one, so nothing needs clearing
+    // and consecutive renders stay free to overlap)
     c->exit_req = 0;
-    HIPCHK(c, hipMemsetAsync(c->d_exit, 0, sizeof(uint32_t), c->stream));
-    c->inputs_dirty = true;
+    c->render_gen.fetch_add(1);
     int rc = ensure_primary(c);
     if (rc != PTK_OK) return rc;
     rc = run_passes(c, first_sample, spp_count, seed, false, accum_ptr(c), c->d_rgb8, c->d_exit, true);
@@ -918,9 +918,9 @@ int ptk_request_exit(ptk_ctx* c)
     c->exit_req = 1;
     // blocks that have not started yet read the flag and return (kernel prologue); written with a
     // blocking copy outside the render stream so it lands while a render is in flight
-    uint32_t one = 1;
+    uint32_t gen = c->render_gen.load();
     (void)hipSetDevice(c->device);
-    (void)hipMemcpy(c->d_exit, &one, sizeof(one), hipMemcpyHostToDevice);
+    (void)hipMemcpy(c->d_exit, &gen, sizeof(gen), hipMemcpyHostToDevice);
     return PTK_OK;
 }
 

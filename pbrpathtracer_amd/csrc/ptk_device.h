@@ -78,7 +78,8 @@ struct RenderParams {
     const float4* primary_rd;   // [H][W] its unit direction (valid with primary_hit)
     float* accum;               // [H][W][3] float RGB, rows bottom-up (mTotalImg)
     uint8_t* rgb8;              // [H][W][3] RGB8, rows bottom-up (mOutImg)
-    const uint32_t* exit_flag;
+    const uint32_t* exit_flag;  // holds the generation of the render an Exit() was aimed at (0: none)
+    uint32_t exit_gen;          // this render's generation: its kernels stand down when *exit_flag == exit_gen
     unsigned long long* stats;  // 7 counters (STATS variant only)
     int num_nodes, num_lights;
     int flat_shade_w, flat_gen_w; // FLAT block-choice weights (eighths) of the shade / camera-ray blocks vs the triangle pass

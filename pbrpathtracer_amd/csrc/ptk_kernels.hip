@@ -451,7 +451,7 @@ template <bool STATS, bool FLAT>
 __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRACE_WAVES_BVH)) void trace_kernel(const RenderParams P)
 {
     __shared__ int lds_stack[FLAT ? 1 : PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
-    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.exit_gen) return;     // Exit() named this render
 
     const int tid = threadIdx.x;
     int* stack = lds_stack + tid;
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void accumulate_kernel(const RenderParam
 {
     // an aborted pass adds nothing: trace waves that saw the exit flag returned without writing their samples, so the
     // sample buffer may hold another pass's values (the reference adds nothing for the rows it skips, pathtracer.cpp:779-780)
-    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.exit_gen) return;     // Exit() named this render
     const int tid = threadIdx.x;
     const int lane = tid & 63, quad = tid >> 6;
     const int owned = blockIdx.x;
