@@ -321,8 +321,9 @@ __global__ __launch_bounds__(kThreads) void level_split_kernel(BNode* __restrict
             L.cmn[a] = fmaxf(N.cmn[a], bl.mn[a]); L.cmx[a] = fminf(N.cmx[a], bl.mx[a]);
             R.cmn[a] = fmaxf(N.cmn[a], br.mn[a]); R.cmx[a] = fminf(N.cmx[a], br.mx[a]);
         }
-        // ... and on its side of the split plane, up to the rounding of the bin index: one bin width of slack
-        const float slack = (hi - lo) / (float)kBins;
+        // ... and on its side of the split plane, up to the rounding of the bin index (bins are clamped, so a centroid a
+        // hair outside these bounds still lands in an end bin: the bounds only steer the binning)
+        const float slack = (hi - lo) * 1e-5f;
         L.cmx[best_axis] = fminf(L.cmx[best_axis], plane + slack);
         R.cmn[best_axis] = fmaxf(R.cmn[best_axis], plane - slack);
         L.count = nl; R.count = count - nl;
