@@ -203,7 +203,8 @@ struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex, walk_iters, w
 // stack[k * PTK_BLOCK].
 struct Walk {
     v3 ro, rd, inv;
-    int node, sp;
+    int node;
+    int* top;                    // this lane's stack top in LDS (== its column's base when empty); unused by the FLAT kernel
     int tri_next, tri_left;      // pending leaf: records [tri_next, tri_next + tri_left) still to test
     Hit best;
     // occl_tri >= 0 marks a shadow ray towards light triangle occl_tri whose sample lies at distance
@@ -214,7 +215,7 @@ struct Walk {
 
     // node: >= 0 interior node to test next; NODE_EXIT nothing left on the node side; any other negative
     // value = a leaf waiting for the triangle queue (tri_next, tri_left) to drain
-    __device__ __forceinline__ void begin(v3 o, v3 d, int num_nodes)
+    __device__ __forceinline__ void begin(v3 o, v3 d, int num_nodes, int* stack)
     {
         ro = o; rd = d;
         // acceleration only: 1-ulp reciprocals are fine for conservative slab tests.  Clamped to +-1e18 so that a ray
@@ -225,7 +226,7 @@ struct Walk {
         inv = V(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e18f, 1e18f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e18f, 1e18f),
                 __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e18f, 1e18f));
         node = num_nodes > 0 ? 0 : NODE_EXIT;
-        sp = 0;
+        top = stack;
         tri_next = 0; tri_left = 0;
         best.tri = PTK_NOHIT; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
     }
@@ -233,9 +234,9 @@ struct Walk {
     template <int STRIDE>
     __device__ __forceinline__ int pop(const int* stack)
     {
-        if (sp == 0) return NODE_EXIT;
-        sp--;
-        return stack[sp * STRIDE];
+        if (top == stack) return NODE_EXIT;
+        top -= STRIDE;
+        return *top;
     }
 };
 
@@ -361,7 +362,7 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
         float4 t0 = ldg4(tp), t1 = ldg4(tp + 1), t2 = ldg4(tp + 2);
         W.tri_next++; W.tri_left--;
         const bool stop = tri_test<STATS>(P, W, t0, t1, t2, rng, ray, cnt);
-        W.sp = stop ? 0 : W.sp;                           // an occluder decides a shadow ray: drop everything
+        W.top = stop ? stack : W.top;                     // an occluder decides a shadow ray: drop everything
         W.tri_left = stop ? 0 : W.tri_left;
         W.node = stop ? NODE_EXIT : W.node;
     }
@@ -402,13 +403,14 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
             key[k] = hit[k] ? ((__float_as_int(tn) & ~3) | k) : 0x7fffffff;
         }
         const int kmin = min(min(key[0], key[1]), min(key[2], key[3]));
-        const int near = kmin & 3;
-        int next = near == 0 ? link0 : (near == 1 ? link1 : (near == 2 ? link2 : link3));
-        // the other children that were hit wait on the stack (two hits: exactly far-after-near; more: slot order)
-        if (hit[0] & (key[0] != kmin)) { stack[W.sp * STRIDE] = link0; W.sp++; }
-        if (hit[1] & (key[1] != kmin)) { stack[W.sp * STRIDE] = link1; W.sp++; }
-        if (hit[2] & (key[2] != kmin)) { stack[W.sp * STRIDE] = link2; W.sp++; }
-        if (hit[3] & (key[3] != kmin)) { stack[W.sp * STRIDE] = link3; W.sp++; }
+        // the nearest child is the one whose key is the minimum (keys of hit children differ in their slot bits); the same
+        // four compares decide which of the others wait on the stack (two hits: exactly far-after-near; more: slot order)
+        const bool o0 = key[0] != kmin, o1 = key[1] != kmin, o2 = key[2] != kmin;
+        int next = !o0 ? link0 : (!o1 ? link1 : (!o2 ? link2 : link3));
+        if (hit[0] & o0) { *W.top = link0; W.top += STRIDE; }
+        if (hit[1] & o1) { *W.top = link1; W.top += STRIDE; }
+        if (hit[2] & o2) { *W.top = link2; W.top += STRIDE; }
+        if (hit[3] & (key[3] != kmin)) { *W.top = link3; W.top += STRIDE; }
         if (kmin == 0x7fffffff) next = W.template pop<STRIDE>(stack);
         W.node = next;
     }
@@ -441,7 +443,8 @@ __device__ __forceinline__ uint32_t pixel_key(uint32_t seed_lo, uint32_t seed_hi
     return hash32(pixel + b);
 }
 
-enum : int { ST_GEN = 0, ST_TRAV = 1, ST_SHADE = 2, ST_DONE = 3, ST_NEED = 4 };
+// (the two states that wait for a camera ray - no unit yet, unit dealt - are the two smallest: one compare counts both)
+enum : int { ST_NEED = 0, ST_GEN = 1, ST_TRAV = 2, ST_SHADE = 3, ST_DONE = 4 };
 
 // FLAT = the scene has so few triangles (P.flat_count <= 16) that no hierarchy is walked: a traversing
 // lane tests every triangle, the records are fetched with SCALAR loads (one s_load per triangle per
@@ -600,10 +603,10 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
 
     // per-lane path state
     Walk W;
-    W.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0);
+    W.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0, stack);
     W.occl_tri = -1; W.occl_limit = 0.0f;
     Walk WS;                        // FLAT only: the shadow ray, tested in the same pass as the bounce ray
-    WS.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0);
+    WS.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0, stack);
     WS.occl_tri = -1; WS.occl_limit = 0.0f;
     v3 L = V(0.0f, 0.0f, 0.0f), T = V(1.0f, 1.0f, 1.0f);
     v3 Tdi = V(0.0f, 0.0f, 0.0f), nextDir = V(0.0f, 0.0f, 1.0f);
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
             if (STATS) cnt.shadow++;                                                              \
             if (!(hit_ && W.best.tri != W.occl_tri)) L = add(L, Tdi);                             \
             W.occl_tri = -1;                                                                      \
-            W.begin(W.ro, nextDir, P.num_nodes);                                                  \
+            W.begin(W.ro, nextDir, P.num_nodes, stack);                                                  \
         }                                                                                         \
         else if (!hit_) PTK_FINISH_PATH();              /* :550 miss -> black */                  \
         else st = ST_SHADE;                                                                       \
@@ -730,6 +733,11 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
         else if (n_trav > 0)
         {
             // ---- BVH walk ----
+            // The loop's bookkeeping is wave-uniform and kept to four ballots per iteration: a lane is walking exactly when
+            // its walk has a leaf triangle pending or a node to visit (W is `done` in every other state, from W.begin's
+            // initial call on), so the two masks that vote the triangle arm also count the walking lanes.
+            int ds = __builtin_amdgcn_readfirstlane(debt_shade), dg = __builtin_amdgcn_readfirstlane(debt_gen);
+            unsigned long long m_tq = __ballot(W.tri_left > 0), m_nr = __ballot(W.node >= 0);
             do
             {
                 if (STATS) { const uint32_t nt = (uint32_t)__popcll(__ballot(st == ST_TRAV)); if (lane == 0) { cnt.walk_iters++; cnt.walk_lanes += nt; } }
@@ -741,8 +749,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 // for half of the walking lanes, thr 4, is the optimum - beyond that the rays whose walk
                 // is finished but for the parked leaf idle too long; a 4-deep leaf ring per lane made
                 // that worse, not better.)
-                const int n_tq = __popcll(__ballot(st == ST_TRAV && W.tri_left > 0));
-                const int n_nr = __popcll(__ballot(st == ST_TRAV && W.node >= 0));
+                const int n_tq = __popcll(m_tq), n_nr = __popcll(m_nr);
                 const bool run_tri_arm = n_tq > 0 && (n_nr == 0 || n_tq * 8 >= P.tri_thr * n_nr);
                 if (STATS && lane == 0 && run_tri_arm) { cnt.tri_execs++; cnt.tri_lanes += (uint32_t)n_tq; }
                 if (st == ST_TRAV)
@@ -750,18 +757,19 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                     walk_step<STATS, PTK_TRACE_BLOCK>(P, W, rng, ray, stack, cnt, run_tri_arm);
                     if (W.done()) PTK_WALK_DONE();
                 }
-                const int nt = __popcll(__ballot(st == ST_TRAV));
+                m_tq = __ballot(W.tri_left > 0); m_nr = __ballot(W.node >= 0);
+                const int nt = __popcll(m_tq | m_nr);
                 const int ns = __popcll(__ballot(st == ST_SHADE));
                 // a lane whose path ended in the walk (its ray left the scene) waits in NEED for a new unit: it runs
                 // up the same debt as a lane waiting for the camera-ray block, and is dealt its unit first
-                const unsigned long long m_nd = __ballot(st == ST_NEED);
-                const int ng = __popcll(__ballot(st == ST_GEN)) + __popcll(m_nd);
+                const int ng = __popcll(__ballot(st < ST_TRAV));
                 const int nl = nt + ns + ng;
-                debt_shade += ns; debt_gen += ng;
-                if (ns > 0 && debt_shade * 8 >= P.shade_thr * (nl - ns)) { run_shade = true; break; }
-                if (ng > 0 && debt_gen * 8 >= P.gen_thr * (nl - ng)) { run_gen = m_nd == 0ull; break; }   // NEED lanes: re-vote via the top of the loop
+                ds += ns; dg += ng;
+                if (ns > 0 && ds * 8 >= P.shade_thr * (nl - ns)) { run_shade = true; break; }
+                if (ng > 0 && dg * 8 >= P.gen_thr * (nl - ng)) { run_gen = __ballot(st == ST_NEED) == 0ull; break; }   // NEED lanes: re-vote via the top of the loop
                 if (nt == 0) break;
             } while (true);
+            debt_shade = ds; debt_gen = dg;
             if (!run_shade && !run_gen) continue;        // the walk ran dry: re-vote
         }
         if (run_shade) debt_shade = 0; else debt_gen = 0;
@@ -951,7 +959,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                                 if (FLAT)
                                 {
                                     // the shadow ray rides along with the bounce ray in the next flat pass
-                                    WS.begin(p, l, P.num_nodes);
+                                    WS.begin(p, l, P.num_nodes, stack);
                                     WS.occl_tri = __float_as_int(l0.w);
                                     WS.occl_limit = sqrtf(dot(dl, dl)) * 0.9999f;
                                 }
@@ -965,7 +973,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                             }
                         }
                         T = mulv(T, weight);
-                        W.begin(next_ro, next_rd, P.num_nodes);
+                        W.begin(next_ro, next_rd, P.num_nodes, stack);
                         st = ST_TRAV;
                     }
                 }
@@ -1000,7 +1008,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                     const float4 c = P.primary_hit[pix], r = P.primary_rd[pix];
                     W.ro = camPos0; W.rd = V(r.x, r.y, r.z);
                     W.best.tri = __float_as_int(c.x); W.best.t = c.y; W.best.u = c.z; W.best.v = c.w;
-                    W.node = NODE_EXIT; W.sp = 0; W.tri_left = 0;
+                    W.node = NODE_EXIT; W.top = stack; W.tri_left = 0;
                     ray = 1;
                     st = ST_SHADE;              // (pixels whose camera ray misses never get here)
                 }
@@ -1022,7 +1030,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                         ro = add(camPos0, add(muls(camRight, offx), muls(camUp, offy)));
                     }
                     v3 rd = normalize(sub(focalPoint, ro));
-                    W.begin(ro, rd, P.num_nodes);
+                    W.begin(ro, rd, P.num_nodes, stack);
                     st = ST_TRAV;
                     if (P.primary_hit)
                     {
@@ -1153,7 +1161,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void primary_hits_kernel(const RenderPar
     v3 rd = normalize(sub(focalPoint, camPos0));
     Walk W;
     W.occl_tri = -1; W.occl_limit = 0.0f;
-    W.begin(camPos0, rd, P.num_nodes);
+    W.begin(camPos0, rd, P.num_nodes, lds_stack + threadIdx.x);
     while (!W.done()) walk_step<false, PTK_BLOCK>(P, W, rng, 0u, lds_stack + threadIdx.x, cnt);
     out[i] = make_float4(__int_as_float(W.best.tri), W.best.t, W.best.u, W.best.v);
     out_rd[i] = make_float4(rd.x, rd.y, rd.z, 0.0f);           // the very floats the camera-ray block computes for a zero lens offset
@@ -1171,7 +1179,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_hits_kernel(const ProbeParams
     v3 rd = V(P.rd[i * 3], P.rd[i * 3 + 1], P.rd[i * 3 + 2]);
     Walk W;
     W.occl_tri = -1; W.occl_limit = 0.0f;
-    W.begin(ro, rd, P.num_nodes);
+    W.begin(ro, rd, P.num_nodes, lds_stack + threadIdx.x);
     while (!W.done()) walk_step<false, PTK_BLOCK>(P, W, rng, 0u, lds_stack + threadIdx.x, cnt);
     bool hit = W.best.tri != PTK_NOHIT;
     P.tri[i] = hit ? W.best.tri : -1;

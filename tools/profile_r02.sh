@@ -23,15 +23,16 @@ if has bench; then
 fi
 if has ktrace; then
   for cfg in C2 C4; do
-    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace_$cfg -- python3 $ROOT/bench.py --config $cfg $(steps_of $cfg) $B > $OUT/ktrace_$cfg.log 2>&1
+    timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktrace_$cfg -- python3 $ROOT/bench.py --config $cfg $(steps_of $cfg) $B > $OUT/ktrace_$cfg.log 2>&1
   done
 fi
+CFGS_TRAFFIC=${CFGS_TRAFFIC:-C2 C3 C4 C5}
 if has traffic; then
-  for cfg in C2 C3 C4 C5; do
+  for cfg in $CFGS_TRAFFIC; do
     i=0
     for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum"; do
       i=$((i+1))
-      rocprofv3 --pmc $set --output-format csv -d $OUT/traffic_$cfg/p$i -- python3 $ROOT/bench.py --config $cfg $(steps_of $cfg) $B > $OUT/traffic_${cfg}_p$i.log 2>&1
+      timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/traffic_$cfg/p$i -- python3 $ROOT/bench.py --config $cfg $(steps_of $cfg) $B > $OUT/traffic_${cfg}_p$i.log 2>&1
     done
   done
 fi
@@ -44,7 +45,7 @@ if has sq; then
              "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_WR"; do
     i=$((i+1))
     for cfg in $CFGS_SQ; do
-      rocprofv3 --pmc $set --output-format csv -d $OUT/sq_$cfg/p$i -- python3 $ROOT/bench.py --config $cfg $(steps_of $cfg) $B > $OUT/sq_${cfg}_p$i.log 2>&1
+      timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/sq_$cfg/p$i -- python3 $ROOT/bench.py --config $cfg $(steps_of $cfg) $B > $OUT/sq_${cfg}_p$i.log 2>&1
     done
   done
 fi
@@ -55,18 +56,19 @@ if has class; then
              "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_BRANCH SQ_INSTS_VALU"; do
     i=$((i+1))
     for cfg in $CFGS_SQ; do
-      rocprofv3 --pmc $set --output-format csv -d $OUT/class_$cfg/p$i -- python3 $ROOT/bench.py --config $cfg $(steps_of $cfg) $B > $OUT/class_${cfg}_p$i.log 2>&1
+      timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/class_$cfg/p$i -- python3 $ROOT/bench.py --config $cfg $(steps_of $cfg) $B > $OUT/class_${cfg}_p$i.log 2>&1
     done
   done
 fi
 if has mem; then
   i=0
-  for set in "TA_TA_BUSY_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum" \
-             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_READ_sum" \
-             "TD_TD_BUSY_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum TCP_TA_TCP_STATE_READ_sum"; do
+  # one or two counters per pass: a larger TA / TCP set is refused ("exceeds the capabilities of the hardware") and the
+  # profiler then hangs instead of exiting, hence the timeouts
+  for set in "TA_TA_BUSY_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TCC_READ_REQ_sum" \
+             "TCP_PENDING_STALL_CYCLES_sum" "TA_FLAT_READ_WAVEFRONTS_sum" "GRBM_GUI_ACTIVE"; do
     i=$((i+1))
-    for cfg in C4 C5; do
-      rocprofv3 --pmc $set --output-format csv -d $OUT/mem_$cfg/p$i -- python3 $ROOT/bench.py --config $cfg $(steps_of $cfg) $B > $OUT/mem_${cfg}_p$i.log 2>&1
+    for cfg in ${CFGS_MEM:-C4 C5}; do
+      timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/mem_$cfg/p$i -- python3 $ROOT/bench.py --config $cfg $(steps_of $cfg) $B > $OUT/mem_${cfg}_p$i.log 2>&1
     done
   done
 fi
