@@ -30,7 +30,9 @@ extern "C" {
 #define PTK_ERR_LIMIT (-4)       /* scene exceeds a kernel limit (BVH depth, index width) */
 
 #define PTK_TILE 16              /* pixel tile edge: one 256-thread block = one 16x16 tile */
+#ifndef PTK_MAX_BVH_DEPTH
 #define PTK_MAX_BVH_DEPTH 32     /* entries of the per-lane LDS traversal stack (bounds what the 4-wide tree may defer at once) */
+#endif
 
 /* replaces Material (mesh.h:21-59) with texture *indices* instead of Image pointers */
 typedef struct ptk_material {

@@ -100,10 +100,32 @@ __device__ __forceinline__ float rcp_ieee_any(float a)
     return 1.0f / a;
 #endif
 }
+// sqrtf(x), BIT FOR BIT the correctly rounded IEEE-754 root: v_sqrt_f32 (1 ulp) and the exact residuals (fma) of its two
+// neighbours - the core of the compiler's own expansion without its range scaling (x < 2^-96 is multiplied by 2^32 first)
+// and special-case selects.  Enumerated over all 2^32 bit patterns (tools/microbench/exact_math.hip, profiles/r02/
+// exact_math.json): identical to sqrtf for +0, +inf and every x >= 2^-104 (the largest input that differs is 0x0b6e9372,
+// where the residuals underflow); anything below - a positive length under 2^-52, which no scene produces, and negative
+// or NaN arguments - takes the compiler's expansion behind a branch that is practically never taken.
+#ifndef PTK_SHORT_SQRT
+#define PTK_SHORT_SQRT 1
+#endif
+__device__ __forceinline__ float sqrt_ieee(float x)
+{
+#if PTK_SHORT_SQRT
+    if (__builtin_expect(!(x >= 0x1p-104f), 0)) return sqrtf(x);          // (zero too: correct either way, and as rare)
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    s = rm <= 0.0f ? sm : s;
+    return rp > 0.0f ? sp : s;
+#else
+    return sqrtf(x);
+#endif
+}
 __device__ __forceinline__ v3 normalize(v3 a)
 {
     float sqr = a.x * a.x + a.y * a.y + a.z * a.z;
-    float inv = rcp_ieee_any(sqrtf(sqr));
+    float inv = rcp_ieee_any(sqrt_ieee(sqr));
     return muls(a, inv);
 }
 __device__ __forceinline__ v3 reflect(v3 I, v3 N)
@@ -432,7 +454,7 @@ __device__ __forceinline__ v3 sample_about(v3 n_for_test, float thr, v3 basis_fr
     float ang = (float)(2.0f * PTK_PI_D * theta);
     float sn, cs;
     sincos_2pi(ang, sn, cs);
-    v3 d = add(add(muls(u, w * cs), muls(v, w * sn)), muls(pole, sqrtf(1.0f - w * w)));
+    v3 d = add(add(muls(u, w * cs), muls(v, w * sn)), muls(pole, sqrt_ieee(1.0f - w * w)));
     return normalize(d);
 }
 
@@ -909,7 +931,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                             }
                             else if (rng.next() < m3.y)         // :706 translucency
                             {
-                                float a = eta * dot(n, rd) + sqrtf(k);
+                                float a = eta * dot(n, rd) + sqrt_ieee(k);
                                 dir = normalize(sub(muls(rd, eta), muls(refractN, a)));   // :708
                                 p = sub(p, muls(muls(n, PTK_EPS), 2.0f));                  // :709
                                 inside = !inside;
@@ -943,7 +965,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                             if (lightId == P.num_lights && lightId > 0) lightId--;
                             const float4* lp = P.lights + (size_t)lightId * LIGHT_F4;
                             float4 l0 = ldg4(lp), l1 = ldg4(lp + 1), l2 = ldg4(lp + 2), l3 = ldg4(lp + 3);
-                            float su = sqrtf(rng.next());
+                            float su = sqrt_ieee(rng.next());
                             float sv = rng.next();
                             float w0 = 1.0f - su, w1 = su * (1.0f - sv), w2 = su * sv;
                             v3 vLight = add(add(muls(V(l0.x, l0.y, l0.z), w0), muls(V(l1.x, l1.y, l1.z), w1)),
@@ -961,12 +983,12 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                                     // the shadow ray rides along with the bounce ray in the next flat pass
                                     WS.begin(p, l, P.num_nodes, stack);
                                     WS.occl_tri = __float_as_int(l0.w);
-                                    WS.occl_limit = sqrtf(dot(dl, dl)) * 0.9999f;
+                                    WS.occl_limit = sqrt_ieee(dot(dl, dl)) * 0.9999f;
                                 }
                                 else
                                 {
                                     W.occl_tri = __float_as_int(l0.w);
-                                    W.occl_limit = sqrtf(dot(dl, dl)) * 0.9999f;
+                                    W.occl_limit = sqrt_ieee(dot(dl, dl)) * 0.9999f;
                                     nextDir = dir;
                                     next_rd = l;
                                 }
@@ -1023,7 +1045,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                     if (P.aperture != 0.0f)
                     {
                         float angle = (float)((double)r1 * 2. * PTK_PI_D);
-                        float radius = sqrtf(r2);
+                        float radius = sqrt_ieee(r2);
                         float sn, cs;
                         sincos_2pi(angle, sn, cs);
                         float offx = (cs * radius) * P.aperture, offy = (sn * radius) * P.aperture;

@@ -38,13 +38,25 @@ __device__ __forceinline__ float sqrt_short(float x)
     return __builtin_fmaf(d, h, g);
 }
 
-struct Report { unsigned long long bad[3]; unsigned first[3][8]; unsigned long long lo_bad[3], hi_bad[3]; };
+// v_sqrt_f32 (1 ulp) and the two neighbour tests of the compiler's own IEEE expansion - exact residuals of the candidates
+// one ulp below and above - WITHOUT that expansion's range scaling (x < 2^-96 is multiplied by 2^32 first) and special-case
+// selects: which inputs need those?
+__device__ __forceinline__ float sqrt_nb(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    s = rm <= 0.0f ? sm : s;
+    return rp > 0.0f ? sp : s;
+}
+
+struct Report { unsigned long long bad[4]; unsigned first[4][8]; unsigned long long lo_bad[4], hi_bad[4]; };
 
 __device__ void note(Report* r, int which, unsigned bits, bool in_domain)
 {
     const unsigned long long k = atomicAdd(&r->bad[which], 1ull);
     if (k < 8) r->first[which][k] = bits;
-    if (in_domain) atomicAdd(&r->lo_bad[which], 1ull);
+    if (in_domain) { atomicAdd(&r->lo_bad[which], 1ull); atomicMax(&r->hi_bad[which], (unsigned long long)bits); }
 }
 
 __global__ void sweep(Report* rep)
@@ -71,6 +83,10 @@ __global__ void sweep(Report* rep)
             const float f = sqrt_short(a);
             const bool refnan = ref != ref;
             if (!(refnan ? (f != f) : (__float_as_uint(f) == __float_as_uint(ref)))) note(rep, 2, bits, dom);
+            // neighbour-test form: domain = +0, positive normals, +inf (everything a squared length or a unit-interval draw can be)
+            const bool dom_nb = bits == 0u || (!(bits >> 31) && ex >= 1u && !is_nan);
+            const float g = sqrt_nb(a);
+            if (!(refnan ? (g != g) : (__float_as_uint(g) == __float_as_uint(ref)))) note(rep, 3, bits, dom_nb);
         }
     }
 }
@@ -83,14 +99,15 @@ int main()
     hipLaunchKernelGGL(sweep, dim3(256 * 16), dim3(256), 0, 0, d);
     CHECK(hipDeviceSynchronize());
     CHECK(hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost));
-    const char* names[3] = { "rcp, two Newton steps", "rcp, one Newton step", "sqrt, rsq + coupled step + residual" };
+    const char* names[4] = { "rcp, two Newton steps", "rcp, one Newton step", "sqrt, rsq + coupled step + residual",
+                             "sqrt, v_sqrt_f32 + residual tests of both neighbours, no range scaling" };
     printf("{\"inputs\": 4294967296, \"rows\": [\n");
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 4; k++)
     {
-        printf(" {\"sequence\": \"%s\", \"mismatches_all_inputs\": %llu, \"mismatches_in_domain\": %llu, \"first_inputs_hex\": [", names[k], h.bad[k], h.lo_bad[k]);
+        printf(" {\"sequence\": \"%s\", \"mismatches_all_inputs\": %llu, \"mismatches_in_domain\": %llu, \"largest_mismatching_input_in_domain_hex\": \"%08llx\", \"first_inputs_hex\": [", names[k], h.bad[k], h.lo_bad[k], h.hi_bad[k]);
         for (int j = 0; j < 8 && (unsigned long long)j < h.bad[k]; j++) printf("%s\"%08x\"", j ? ", " : "", h.first[k][j]);
-        printf("]}%s\n", k < 2 ? "," : "");
+        printf("]}%s\n", k < 3 ? "," : "");
     }
-    printf("], \"domain\": \"rcp: normal a with 2^-126 <= |a| <= 2^126 (biased exponent 1..252); sqrt: positive normal x\"}\n");
+    printf("], \"domain\": \"rcp: normal a with 2^-126 <= |a| <= 2^126 (biased exponent 1..252); sqrt: positive normal x; neighbour-test sqrt: +0, positive normal x, +inf\"}\n");
     return 0;
 }

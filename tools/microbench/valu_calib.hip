@@ -120,6 +120,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define A_PKMUL(k) "v_pk_mul_f32 %" #k ", %" #k ", %8\n"
 #define A_PKADD(k) "v_pk_add_f32 %" #k ", %" #k ", %9\n"
 #define A_PKFMA(k) "v_pk_fma_f32 %" #k ", %" #k ", %8, %9\n"
+#define A_FMAMIX(k) "v_fma_mix_f32 %" #k ", %" #k ", %8, %9 op_sel_hi:[1,0,0]\n"
+#define A_FMAMIXHI(k) "v_fma_mix_f32 %" #k ", %" #k ", %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+#define A_BFI(k) "v_bfi_b32 %" #k ", %8, %" #k ", %9\n"
+#define A_MED3(k) "v_med3_f32 %" #k ", %" #k ", %8, %9\n"
+#define A_LSHLOR(k) "v_lshl_or_b32 %" #k ", %" #k ", 8, %8\n"
+#define A_CVTF16(k) "v_cvt_f32_f16 %" #k ", %" #k "\n"
+#define A_CMPE64(k) "v_cmp_lt_f32_e64 s[20:21], %" #k ", %8\n"
 #define A_FMA64(k) "v_fma_f64 %" #k ", %" #k ", %8, %9\n"
 #define A_MUL64(k) "v_mul_f64 %" #k ", %" #k ", %8\n"
 #define A_ADD64(k) "v_add_f64 %" #k ", %" #k ", %9\n"
@@ -159,6 +166,13 @@ KERNEL_F32(cvt_f32_u32, S8(A_CVTF32U32))
 KERNEL_F32(lshl_add_u32, S8(A_LSHLADD))
 KERNEL_F32(perm, S8(A_PERM))
 KERNEL_F32(mov, S8(A_MOV))
+KERNEL_F32(fma_mix, S8(A_FMAMIX))
+KERNEL_F32(fma_mix_hi, S8(A_FMAMIXHI))
+KERNEL_F32(bfi, S8(A_BFI))
+KERNEL_F32(med3, S8(A_MED3))
+KERNEL_F32(lshl_or, S8(A_LSHLOR))
+KERNEL_F32(cvt_f32_f16, S8(A_CVTF16))
+KERNEL_F32(cmp_e64, S8(A_CMPE64))
 KERNEL_PK(pk_mul, S8(A_PKMUL))
 KERNEL_PK(pk_add, S8(A_PKADD))
 KERNEL_PK(pk_fma, S8(A_PKFMA))
@@ -254,6 +268,27 @@ __global__ __launch_bounds__(64, 8) void k_lds_stack(float* out, int iters, unsi
     out[1 + blockIdx.x * 64 + threadIdx.x] = (float)v;
 }
 
+// The node arm's byte -> float conversion through f16 DENORMALS: a half whose bits are 0x00NN is NN * 2^-24 exactly, and
+// v_fma_mix_f32 converts it on the fly, so fma(NN * 2^-24, A * 2^24, B) must equal fma((float)NN, A, B) bit for bit
+// (power-of-two scalings are exact).  Checked for every byte against a spread of A and B.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__global__ void k_mix_check(unsigned* mismatches)
+{
+    const unsigned q = threadIdx.x & 255u;
+    const unsigned packed = q | (q << 16);
+    const h2 h = __builtin_bit_cast(h2, packed);
+    unsigned bad = 0;
+    for (int i = 0; i < 4096; i++)
+    {
+        const float A = __uint_as_float(0x2f800000u + (unsigned)(blockIdx.x * 4096 + i) * 2654435761u % 0x20000000u) * ((i & 1) ? -1.0f : 1.0f);
+        const float B = __uint_as_float(0x30000000u + (unsigned)(blockIdx.x * 4096 + i) * 40503u % 0x1f000000u) * ((i & 2) ? -1.0f : 1.0f);
+        const float ref = __builtin_fmaf((float)q, A, B);
+        const float lo = __builtin_fmaf((float)h.x, A * 16777216.0f, B), hi = __builtin_fmaf((float)h.y, A * 16777216.0f, B);
+        bad += (__float_as_uint(ref) != __float_as_uint(lo)) + (__float_as_uint(ref) != __float_as_uint(hi));
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 struct Entry { const char* name; void (*fn)(float*, int, unsigned long long*); int per_iter; const char* note; };
 #define E(n, per, note) { #n, k_##n, per, note }
 static const Entry entries[] = {
@@ -266,6 +301,8 @@ static const Entry entries[] = {
     E(cvt_f32_ubyte, 32, "v_cvt_f32_ubyte0"), E(cvt_i32_f32, 32, "v_cvt_i32_f32"),
     E(rcp, 32, "v_rcp_f32"), E(sqrt, 32, "v_sqrt_f32"), E(rsq, 32, "v_rsq_f32"),
     E(div_scale, 32, "v_div_scale_f32"), E(div_fmas, 32, "v_div_fmas_f32"), E(div_fixup, 32, "v_div_fixup_f32"),
+    E(fma_mix, 32, "v_fma_mix_f32, src0 = low f16 half"), E(fma_mix_hi, 32, "v_fma_mix_f32, src0 = high f16 half"), E(bfi, 32, "v_bfi_b32"), E(med3, 32, "v_med3_f32"),
+    E(lshl_or, 32, "v_lshl_or_b32"), E(cvt_f32_f16, 32, "v_cvt_f32_f16"), E(cmp_e64, 32, "v_cmp_lt_f32_e64 -> SGPR pair"),
     E(pk_mul, 32, "v_pk_mul_f32 (2 results per lane)"), E(pk_add, 32, "v_pk_add_f32"), E(pk_fma, 32, "v_pk_fma_f32"),
     E(fma_f64, 32, "v_fma_f64"), E(mul_f64, 32, "v_mul_f64"), E(add_f64, 32, "v_add_f64"),
     E(ieee_div, 32, "1.0f / x as hipcc expands it (per division)"), E(ieee_sqrt, 32, "sqrtf(x) + 1 as hipcc expands it (per sqrt)"),
@@ -320,6 +357,10 @@ int main(int argc, char** argv)
         printf("}");
         fflush(stdout);
     }
-    printf("\n]}\n");
+    unsigned* d_bad; unsigned h_bad = 0;
+    CHECK(hipMalloc(&d_bad, 4)); CHECK(hipMemset(d_bad, 0, 4));
+    hipLaunchKernelGGL(k_mix_check, dim3(1024), dim3(256), 0, 0, d_bad);
+    CHECK(hipMemcpy(&h_bad, d_bad, 4, hipMemcpyDeviceToHost));
+    printf("\n],\n \"fma_mix_f16_denormal_check\": {\"what\": \"fma(byte as f16 denormal, A * 2^24, B) vs fma((float)byte, A, B), 256 bytes x 2 halves x 4 M (A, B) pairs\", \"mismatches\": %u}}\n", h_bad);
     return 0;
 }

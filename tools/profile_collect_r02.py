@@ -63,7 +63,7 @@ for c in ("C1", "C2", "C3", "C4", "C5"):
 for c in ("C2", "C4"):
     for f in glob.glob(f"{src}/ktrace_{c}/**/*_kernel_stats.csv", recursive=True):
         shutil.copy(f, os.path.join(dst, f"rocprofv3_kernel_stats_{c}.csv"))
-for name in ("valu_calibration.json", "gather_ceiling.json"):
+for name in ("valu_calibration.json", "gather_ceiling.json", "exact_math.json"):
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, name))
