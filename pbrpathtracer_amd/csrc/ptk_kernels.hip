@@ -106,6 +106,9 @@ __device__ __forceinline__ float rcp_ieee_any(float a)
 // exact_math.json): identical to sqrtf for +0, +inf and every x >= 2^-104 (the largest input that differs is 0x0b6e9372,
 // where the residuals underflow); anything below - a positive length under 2^-52, which no scene produces, and negative
 // or NaN arguments - takes the compiler's expansion behind a branch that is practically never taken.
+#ifndef PTK_NODE_PREFETCH
+#define PTK_NODE_PREFETCH 1
+#endif
 #ifndef PTK_SHORT_SQRT
 #define PTK_SHORT_SQRT 1
 #endif
@@ -378,6 +381,17 @@ template <bool STATS, int STRIDE, class PT>
 __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, uint32_t ray, int* stack, Counters& cnt,
                                           const bool run_tri_arm = true)
 {
+#if PTK_NODE_PREFETCH
+    // the node record of arm B is requested BEFORE arm A runs, so that its round trip overlaps arm A's loads and arithmetic
+    // (one memory latency per iteration instead of two; the compiler would otherwise issue it after arm A's join)
+    float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q1 = q0, q2 = q0, q3 = q0;
+    if (W.node >= 0)
+    {
+        const float4* np = P.nodes + (size_t)W.node * NODE_F4;
+        q0 = ldg4(np); q1 = ldg4(np + 1); q2 = ldg4(np + 2); q3 = ldg4(np + 3);
+    }
+    asm volatile("" ::: "memory");
+#endif
     if (run_tri_arm && W.tri_left > 0)                    // ---- arm A: one triangle
     {
         const float4* tp = P.tris + (size_t)W.tri_next * TRI_F4;
@@ -390,8 +404,10 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
     }
     if (W.node >= 0)                                      // ---- arm B: one 4-wide interior node
     {
+#if !PTK_NODE_PREFETCH
         const float4* np = P.nodes + (size_t)W.node * NODE_F4;
         const float4 q0 = ldg4(np), q1 = ldg4(np + 1), q2 = ldg4(np + 2), q3 = ldg4(np + 3);
+#endif
         if (STATS) { cnt.nodes++; cnt.cur_nodes++; }
         // child planes live on the node's 8-bit grid: plane = origin + q * scale, so along the ray
         //   t = (plane - ro) * inv = q * (scale * inv) + (origin - ro) * inv = fma(q, A, B)
