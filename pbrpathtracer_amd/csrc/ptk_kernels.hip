@@ -826,8 +826,13 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 int matid = mbits & 0x7fffffff;
                 bool smoothing = mbits < 0;
                 const float4* mp = P.mats + (size_t)matid * MAT_F4;
-                float4 m0 = ldg4(mp), m3 = ldg4(mp + 3);
+                // the whole 96-byte material in one batch (two of its words are only needed further down: asked for there,
+                // they cost the block another memory round trip), and the vertex normals of a smoothed triangle with it
+                float4 m0 = ldg4(mp), m1 = ldg4(mp + 1), m2 = ldg4(mp + 2), m3 = ldg4(mp + 3);
                 float4 m4f = ldg4(mp + 4), m5f = ldg4(mp + 5);
+                float4 sn2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sn3 = sn2, sn4 = sn2;
+                if (smoothing) { sn2 = ldg4(sp4 + 2); sn3 = ldg4(sp4 + 3); sn4 = ldg4(sp4 + 4); }
+                asm volatile("" ::: "memory");
                 int tex_diffuse = __float_as_int(m4f.x), tex_normal = __float_as_int(m4f.y);
                 int tex_emiss = __float_as_int(m4f.z), tex_rough = __float_as_int(m4f.w);
                 int tex_metal = __float_as_int(m5f.x);
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 v3 n = V(s0.x, s0.y, s0.z);
                 if (smoothing)                                  // :556, GetSmoothNormal :538-543
                 {
-                    float4 s2 = ldg4(sp4 + 2), s3 = ldg4(sp4 + 3), s4 = ldg4(sp4 + 4);
+                    const float4 s2 = sn2, s3 = sn3, s4 = sn4;
                     float w = 1.0f - h.u - h.v;
                     v3 n1 = V(s2.z, s2.w, s3.x), n2 = V(s3.y, s3.z, s3.w), n3 = V(s4.x, s4.y, s4.z);
                     v3 sn = add(add(muls(n1, w), muls(n2, h.u)), muls(n3, h.v));
@@ -872,7 +877,6 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 if (!(iter < P.max_depth)) ended = true;        // :571 terminal bounce: no emission
                 else
                 {
-                    float4 m1 = ldg4(mp + 1), m2 = ldg4(mp + 2);
                     v3 diffuse = V(m0.x, m0.y, m0.z);
                     if (tex_diffuse >= 0) { float4 c = tex2d(P, tex_diffuse, uvx, uvy); diffuse = V(c.x, c.y, c.z); if (STATS) cnt.tex++; }
                     v3 emiss = V(m2.x, m2.y, m2.z);
