@@ -647,7 +647,7 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     dfree(c->d_texinfo); dfree(c->d_texels);
     c->have_scene = false;
     auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
-        size_t alloc = bytes ? bytes : 16;
+        size_t alloc = bytes ? bytes : 64;      // (never null: the walk reads node 0 unconditionally)
         hipError_t e = hipMalloc(dst, alloc);
         if (e != hipSuccess) return e;
         if (bytes) return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);

@@ -384,12 +384,10 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
 #if PTK_NODE_PREFETCH
     // the node record of arm B is requested BEFORE arm A runs, so that its round trip overlaps arm A's loads and arithmetic
     // (one memory latency per iteration instead of two; the compiler would otherwise issue it after arm A's join)
-    float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q1 = q0, q2 = q0, q3 = q0;
-    if (W.node >= 0)
-    {
-        const float4* np = P.nodes + (size_t)W.node * NODE_F4;
-        q0 = ldg4(np); q1 = ldg4(np + 1); q2 = ldg4(np + 2); q3 = ldg4(np + 3);
-    }
+    // (unconditional: a lane without a node reads the root - every such lane the same 64 bytes - which is cheaper than
+    // a branch around the loads and zeroing sixteen registers for the lanes that skip them)
+    const float4* np = P.nodes + (size_t)max(W.node, 0) * NODE_F4;
+    const float4 q0 = ldg4(np), q1 = ldg4(np + 1), q2 = ldg4(np + 2), q3 = ldg4(np + 3);
     asm volatile("" ::: "memory");
 #endif
     if (run_tri_arm && W.tri_left > 0)                    // ---- arm A: one triangle
@@ -776,6 +774,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
             // initial call on), so the two masks that vote the triangle arm also count the walking lanes.
             int ds = __builtin_amdgcn_readfirstlane(debt_shade), dg = __builtin_amdgcn_readfirstlane(debt_gen);
             unsigned long long m_tq = __ballot(W.tri_left > 0), m_nr = __ballot(W.node >= 0);
+            bool want_shade = false, want_gen = false;
             do
             {
                 if (STATS) { const uint32_t nt = (uint32_t)__popcll(__ballot(st == ST_TRAV)); if (lane == 0) { cnt.walk_iters++; cnt.walk_lanes += nt; } }
@@ -788,7 +787,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 // is finished but for the parked leaf idle too long; a 4-deep leaf ring per lane made
                 // that worse, not better.)
                 const int n_tq = __popcll(m_tq), n_nr = __popcll(m_nr);
-                const bool run_tri_arm = n_tq > 0 && (n_nr == 0 || n_tq * 8 >= P.tri_thr * n_nr);
+                const bool run_tri_arm = (n_tq > 0) & ((n_nr == 0) | (n_tq * 8 >= P.tri_thr * n_nr));      // (bitwise: no scalar branches)
                 if (STATS && lane == 0 && run_tri_arm) { cnt.tri_execs++; cnt.tri_lanes += (uint32_t)n_tq; }
                 if (st == ST_TRAV)
                 {
@@ -803,10 +802,13 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 const int ng = __popcll(__ballot(st < ST_TRAV));
                 const int nl = nt + ns + ng;
                 ds += ns; dg += ng;
-                if (ns > 0 && ds * 8 >= P.shade_thr * (nl - ns)) { run_shade = true; break; }
-                if (ng > 0 && dg * 8 >= P.gen_thr * (nl - ng)) { run_gen = __ballot(st == ST_NEED) == 0ull; break; }   // NEED lanes: re-vote via the top of the loop
-                if (nt == 0) break;
+                // one exit test per iteration, which exit it was is sorted out after the loop
+                want_shade = (ns > 0) & (ds * 8 >= P.shade_thr * (nl - ns));
+                want_gen = (ng > 0) & (dg * 8 >= P.gen_thr * (nl - ng));
+                if (want_shade | want_gen | (nt == 0)) break;
             } while (true);
+            if (want_shade) run_shade = true;
+            else if (want_gen) run_gen = __ballot(st == ST_NEED) == 0ull;      // NEED lanes: re-vote via the top of the loop
             debt_shade = ds; debt_gen = dg;
             if (!run_shade && !run_gen) continue;        // the walk ran dry: re-vote
         }
