@@ -19,8 +19,10 @@ step's trace kernel.
 Prints ONE JSON line on rank 0 (see the driver contract) including
   roofline       the roof that bounds trace_kernel, chosen from the data: "valu" when the PMC-measured HBM traffic
                  (profiles/traffic_<config>.json) is under 10 % of the HBM peak, else "hbm".  VALU: SURVEY 8(d4)'s
-                 algorithmic flops / ms_per_step vs the 157.3 TFLOP/s FP32 vector peak.  The HBM figures (8(d4)'s
-                 algorithmic bytes and the counter traffic) stay beside it.
+                 algorithmic flops / ms_per_step vs the 157.3 TFLOP/s FP32 vector peak.  HBM: 8(d4)'s algorithmic
+                 bytes / launch duration - or, where the caches serve most of those (the rate asked exceeds what the
+                 counters saw leave the L2), the counter traffic itself.  Both sets of figures stay beside the head,
+                 with the offline instruction-class bounds of the VALU pipe's occupancy (profiles/r02/).
   cpu_baseline   both CPU modes of SURVEY 8(d5), timed on this box's host cores on a bounded sample of the same
                  workload (N = 1 only): the reference's own OpenMP path as shipped (oracle/_ref, built from
                  /root/reference by __graft_entry__.build()) and the oracle port with a per-path RNG on all cores;
