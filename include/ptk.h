@@ -229,6 +229,10 @@ int ptk_download_bvh(ptk_ctx* ctx, float* nodes16, int32_t* leaf_order);
 /* probes used by the parity tests (same semantics as the kernels' device functions) */
 int ptk_probe_hits(ptk_ctx* ctx, int n, const float* ro, const float* rd, int32_t* tri, float* tuv);
 int ptk_probe_primary_dirs(ptk_ctx* ctx, float* host_out /* [H][W][3] top-down */);
+/* the kernels' exact-arithmetic helpers on an array: op 0 = the short reciprocal (valid for 2^-126 <= |a| <= 2^126), 1 = the
+ * reciprocal with IEEE special cases, 2 = the short square root, 3 = 1 / sqrt(x) as the normalisations compute it.  Each must
+ * return the bits of the IEEE-754 operation the reference's CPU code performs (1.0f / a, sqrtf(x)). */
+int ptk_probe_math(ptk_ctx* ctx, int op, int n, const float* in, float* out);
 
 #ifdef __cplusplus
 }

@@ -1340,6 +1340,24 @@ int ptk_probe_hits(ptk_ctx* c, int n, const float* ro, const float* rd, int32_t*
     return PTK_OK;
 }
 
+int ptk_probe_math(ptk_ctx* c, int op, int n, const float* in, float* out)
+{
+    if (!c || op < 0 || op > 3 || n < 0 || (n > 0 && (!in || !out))) return PTK_ERR_BAD_ARG;
+    if (n == 0) return PTK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    const size_t bytes = (size_t)n * sizeof(float);
+    hipError_t e = hipMalloc(&d_in, bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_out, bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) { launch_probe_math(op, d_in, d_out, n, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, PTK_ERR_HIP, hipGetErrorString(e));
+    return PTK_OK;
+}
+
 int ptk_probe_primary_dirs(ptk_ctx* c, float* host_out)
 {
     if (!c || !host_out) return PTK_ERR_BAD_ARG;

@@ -125,5 +125,6 @@ void launch_unpack_all(const float* packed, const long long* bases, float* image
 void launch_primary(const PrimaryParams& p, hipStream_t stream);
 void launch_primary_hits(const RenderParams& p, float4* out, float4* out_rd, hipStream_t stream);
 void launch_probe(const ProbeParams& p, hipStream_t stream);
+void launch_probe_math(int op, const float* d_in, float* d_out, int n, hipStream_t stream);
 
 }  // namespace ptk

@@ -1230,6 +1230,20 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_hits_kernel(const ProbeParams
     P.tuv[i * 3] = hit ? W.best.t : 0.0f; P.tuv[i * 3 + 1] = hit ? W.best.u : 0.0f; P.tuv[i * 3 + 2] = hit ? W.best.v : 0.0f;
 }
 
+// Parity probe of the exact-arithmetic helpers the kernels use in place of `1.0f / a` and `sqrtf(x)` (op 0: rcp_ieee,
+// 1: rcp_ieee_any, 2: sqrt_ieee, 3: the normalisation's 1 / sqrt(x)): the tests hold them against the host's IEEE results.
+__global__ __launch_bounds__(PTK_BLOCK) void probe_math_kernel(int op, const float* __restrict__ in, float* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i];
+    out[i] = op == 0 ? rcp_ieee(x) : (op == 1 ? rcp_ieee_any(x) : (op == 2 ? sqrt_ieee(x) : rcp_ieee_any(sqrt_ieee(x))));
+}
+void launch_probe_math(int op, const float* d_in, float* d_out, int n, hipStream_t stream)
+{
+    if (n > 0) hipLaunchKernelGGL(probe_math_kernel, dim3((n + PTK_BLOCK - 1) / PTK_BLOCK), dim3(PTK_BLOCK), 0, stream, op, d_in, d_out, n);
+}
+
 struct QueueGeometry { int w[QG_WORDS]; };
 __global__ void queue_init_kernel(unsigned* block, const QueueGeometry geo, const unsigned* live_count)
 {

@@ -63,7 +63,7 @@ SYMBOLS = [
     "ptk_request_exit", "ptk_synchronize", "ptk_last_error", "ptk_accum_device_ptr", "ptk_rgb8_device_ptr",
     "ptk_bind_accum", "ptk_set_stream", "ptk_gather_accum", "ptk_set_option", "ptk_last_render_ms",
     "ptk_last_kernel_ms", "ptk_collect_stats",
-    "ptk_bvh_info", "ptk_bvh_layout", "ptk_upload_timing", "ptk_download_bvh", "ptk_probe_hits", "ptk_probe_primary_dirs", "ptk_host_alloc", "ptk_host_free",
+    "ptk_bvh_info", "ptk_bvh_layout", "ptk_upload_timing", "ptk_download_bvh", "ptk_probe_hits", "ptk_probe_primary_dirs", "ptk_probe_math", "ptk_host_alloc", "ptk_host_free",
     "ptk_packed_floats", "ptk_packed_layout", "ptk_comm_unique_id", "ptk_comm_init", "ptk_comm_destroy",
     "ptk_gather_wait", "ptk_read_gathered", "ptk_gathered_device_ptr", "ptk_probe_pack", "ptk_probe_unpack",
 ]
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
     L.ptk_download_bvh.argtypes = [vp, vp, vp]
     L.ptk_upload_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.ptk_probe_hits.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.ptk_probe_math.argtypes = [vp, i32, i32, vp, vp]
     L.ptk_probe_primary_dirs.argtypes = [vp, vp]
     _lib = L
     return L
@@ -329,6 +330,13 @@ class Context:
         tri = np.empty(n, np.int32); tuv = np.empty((n, 3), np.float32)
         self._chk(self.L.ptk_probe_hits(self.h, n, ro.ctypes.data, rd.ctypes.data, tri.ctypes.data, tuv.ctypes.data), "ptk_probe_hits")
         return tri, tuv
+
+    def probe_math(self, op: int, x: np.ndarray) -> np.ndarray:
+        """The kernels' exact-arithmetic helpers on an array (op 0 rcp, 1 rcp with special cases, 2 sqrt, 3 1/sqrt)."""
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty_like(x)
+        self._chk(self.L.ptk_probe_math(self.h, op, x.size, x.ctypes.data, out.ctypes.data), "ptk_probe_math")
+        return out
 
     def primary_dirs(self) -> np.ndarray:
         out = np.empty((self.height, self.width, 3), np.float32)
