@@ -229,6 +229,10 @@ int ptk_download_bvh(ptk_ctx* ctx, float* nodes16, int32_t* leaf_order);
 /* probes used by the parity tests (same semantics as the kernels' device functions) */
 int ptk_probe_hits(ptk_ctx* ctx, int n, const float* ro, const float* rd, int32_t* tri, float* tuv);
 int ptk_probe_primary_dirs(ptk_ctx* ctx, float* host_out /* [H][W][3] top-down */);
+/* DirectIllumimation (pathtracer.cpp:505-531) at n surface points with its three draws (light choice, the two of SampleTriangle)
+ * on tape: light sample, n.l test, shadow walk and visibility rule exactly as the trace kernel applies them; out3 = the value
+ * the reference's function returns (zero when unlit).  Inputs / output [n][3]. */
+int ptk_probe_direct(ptk_ctx* ctx, int n, const float* points, const float* normals, const float* diffuse, const float* tape3, float* out3);
 /* the kernels' exact-arithmetic helpers on an array: op 0 = the short reciprocal (valid for 2^-126 <= |a| <= 2^126), 1 = the
  * reciprocal with IEEE special cases, 2 = the short square root, 3 = 1 / sqrt(x) as the normalisations compute it.  Each must
  * return the bits of the IEEE-754 operation the reference's CPU code performs (1.0f / a, sqrtf(x)). */

@@ -1325,7 +1325,7 @@ int ptk_probe_hits(ptk_ctx* c, int n, const float* ro, const float* rd, int32_t*
     if (e == hipSuccess) e = hipMemcpyAsync(d_rd, rd, b3, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
     {
-        ProbeParams p;
+        ProbeParams p = {};
         p.nodes = c->d_nodes; p.tris = c->d_tris; p.shade = c->d_shade; p.mats = c->d_mats;
         p.texinfo = c->d_texinfo; p.texels = c->d_texels; p.ro = d_ro; p.rd = d_rd; p.tri = d_tri; p.tuv = d_tuv;
         p.n = n; p.num_nodes = c->num_nodes;
@@ -1336,6 +1336,34 @@ int ptk_probe_hits(ptk_ctx* c, int n, const float* ro, const float* rd, int32_t*
     if (e == hipSuccess) e = hipMemcpyAsync(tuv, d_tuv, b3, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_ro); (void)hipFree(d_rd); (void)hipFree(d_tuv); (void)hipFree(d_tri);
+    if (e != hipSuccess) return fail(c, PTK_ERR_HIP, hipGetErrorString(e));
+    return PTK_OK;
+}
+
+int ptk_probe_direct(ptk_ctx* c, int n, const float* pts, const float* normals, const float* diffuse, const float* tape3, float* out3)
+{
+    if (!c || n < 0 || (n > 0 && (!pts || !normals || !diffuse || !tape3 || !out3))) return PTK_ERR_BAD_ARG;
+    if (!c->have_scene) return fail(c, PTK_ERR_BAD_ARG, "ptk_upload_scene has not been called");
+    if (n == 0) return PTK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t b3 = (size_t)n * 3 * sizeof(float);
+    float* d[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    const float* src[4] = { pts, normals, diffuse, tape3 };
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipMalloc(&d[k], b3);
+    for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipMemcpyAsync(d[k], src[k], b3, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+    {
+        ProbeParams p = {};
+        p.nodes = c->d_nodes; p.tris = c->d_tris; p.shade = c->d_shade; p.mats = c->d_mats;
+        p.texinfo = c->d_texinfo; p.texels = c->d_texels; p.lights = c->d_lights; p.num_lights = c->num_lights;
+        p.n = n; p.num_nodes = c->num_nodes;
+        launch_probe_direct(p, d[0], d[1], d[2], d[3], d[4], c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out3, d[4], b3, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    for (int k = 0; k < 5; k++) (void)hipFree(d[k]);
     if (e != hipSuccess) return fail(c, PTK_ERR_HIP, hipGetErrorString(e));
     return PTK_OK;
 }

@@ -114,6 +114,8 @@ struct ProbeParams {
     int32_t* tri;
     float* tuv;
     int n, num_nodes;
+    const float4* lights;       // probe_direct only
+    int num_lights;
 };
 
 void launch_trace(const RenderParams& p, int num_subtiles, int resident_waves, hipStream_t stream, bool stats);
@@ -125,6 +127,7 @@ void launch_unpack_all(const float* packed, const long long* bases, float* image
 void launch_primary(const PrimaryParams& p, hipStream_t stream);
 void launch_primary_hits(const RenderParams& p, float4* out, float4* out_rd, hipStream_t stream);
 void launch_probe(const ProbeParams& p, hipStream_t stream);
+void launch_probe_direct(const ProbeParams& p, const float* pts, const float* nrm, const float* dif, const float* tape, float* out, hipStream_t stream);
 void launch_probe_math(int op, const float* d_in, float* d_out, int n, hipStream_t stream);
 
 }  // namespace ptk

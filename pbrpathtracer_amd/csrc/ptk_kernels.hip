@@ -479,6 +479,34 @@ __device__ __forceinline__ uint32_t pixel_key(uint32_t seed_lo, uint32_t seed_hi
     return hash32(pixel + b);
 }
 
+// DirectIllumimation's sampling half (pathtracer.cpp:494-521, 527-530; SampleTriangle :494-503): picks a light triangle and a
+// point on it from three draws, in the reference's order, and returns false when the surface faces away (:518-520).  Its
+// visibility half (:522-526, closest hit along l is the light) is the shadow walk the caller starts: towards `l`, with
+// occl_tri = light_tri and occl_limit = |dl| * 0.9999.  di is the value DirectIllumimation returns when that walk finds the
+// light (:530).
+template <class PT>
+__device__ __forceinline__ bool sample_direct_light(const PT& P, v3 p, v3 n, v3 diffuse, float u_light, float u_su, float u_sv,
+                                                    v3& l, v3& dl, v3& di, int& light_tri)
+{
+    int lightId = (int)floorf(u_light * (float)P.num_lights);
+    if (lightId == P.num_lights && lightId > 0) lightId--;
+    const float4* lp = P.lights + (size_t)lightId * LIGHT_F4;
+    float4 l0 = ldg4(lp), l1 = ldg4(lp + 1), l2 = ldg4(lp + 2), l3 = ldg4(lp + 3);
+    float su = sqrt_ieee(u_su);
+    float sv = u_sv;
+    float w0 = 1.0f - su, w1 = su * (1.0f - sv), w2 = su * sv;
+    v3 vLight = add(add(muls(V(l0.x, l0.y, l0.z), w0), muls(V(l1.x, l1.y, l1.z), w1)),
+                    muls(V(l2.x, l2.y, l2.z), w2));
+    dl = sub(vLight, p);
+    l = normalize(dl);
+    float ndl = dot(neg(n), neg(l));
+    light_tri = __float_as_int(l0.w);
+    if (!(ndl > 0.0f)) return false;
+    v3 lColor = V(l1.w, l2.w, l3.x);
+    di = muls(mulv(lColor, diffuse), ndl);      // :530
+    return true;
+}
+
 // (the two states that wait for a camera ray - no unit yet, unit dealt - are the two smallest: one compare counts both)
 enum : int { ST_NEED = 0, ST_GEN = 1, ST_TRAV = 2, ST_SHADE = 3, ST_DONE = 4 };
 
@@ -983,33 +1011,22 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                         if (diffuse_bounce && P.num_lights > 0)
                         {
                             // DirectIllumimation + SampleTriangle, pathtracer.cpp:494-531
-                            int lightId = (int)floorf(rng.next() * (float)P.num_lights);
-                            if (lightId == P.num_lights && lightId > 0) lightId--;
-                            const float4* lp = P.lights + (size_t)lightId * LIGHT_F4;
-                            float4 l0 = ldg4(lp), l1 = ldg4(lp + 1), l2 = ldg4(lp + 2), l3 = ldg4(lp + 3);
-                            float su = sqrt_ieee(rng.next());
-                            float sv = rng.next();
-                            float w0 = 1.0f - su, w1 = su * (1.0f - sv), w2 = su * sv;
-                            v3 vLight = add(add(muls(V(l0.x, l0.y, l0.z), w0), muls(V(l1.x, l1.y, l1.z), w1)),
-                                            muls(V(l2.x, l2.y, l2.z), w2));
-                            v3 dl = sub(vLight, p);
-                            v3 l = normalize(dl);
-                            float ndl = dot(neg(n), neg(l));
-                            if (ndl > 0.0f)
+                            const float u_light = rng.next(), u_su = rng.next(), u_sv = rng.next();
+                            v3 l, dl, di;
+                            int light_tri;
+                            if (sample_direct_light(P, p, n, diffuse, u_light, u_su, u_sv, l, dl, di, light_tri))
                             {
-                                v3 lColor = V(l1.w, l2.w, l3.x);
-                                v3 di = muls(mulv(lColor, diffuse), ndl);      // :530
                                 Tdi = mulv(T, di);
                                 if (FLAT)
                                 {
                                     // the shadow ray rides along with the bounce ray in the next flat pass
                                     WS.begin(p, l, P.num_nodes, stack);
-                                    WS.occl_tri = __float_as_int(l0.w);
+                                    WS.occl_tri = light_tri;
                                     WS.occl_limit = sqrt_ieee(dot(dl, dl)) * 0.9999f;
                                 }
                                 else
                                 {
-                                    W.occl_tri = __float_as_int(l0.w);
+                                    W.occl_tri = light_tri;
                                     W.occl_limit = sqrt_ieee(dot(dl, dl)) * 0.9999f;
                                     nextDir = dir;
                                     next_rd = l;
@@ -1228,6 +1245,35 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_hits_kernel(const ProbeParams
     bool hit = W.best.tri != PTK_NOHIT;
     P.tri[i] = hit ? W.best.tri : -1;
     P.tuv[i * 3] = hit ? W.best.t : 0.0f; P.tuv[i * 3 + 1] = hit ? W.best.u : 0.0f; P.tuv[i * 3 + 2] = hit ? W.best.v : 0.0f;
+}
+
+// Parity probe of DirectIllumimation (pathtracer.cpp:505-531) with its three draws on tape: the sampling half above, then the
+// shadow walk and the visibility rule exactly as trace_kernel applies them (PTK_WALK_DONE).
+__global__ __launch_bounds__(PTK_BLOCK) void probe_direct_kernel(const ProbeParams P, const float* __restrict__ pts, const float* __restrict__ nrm,
+                                                                 const float* __restrict__ dif, const float* __restrict__ tape, float* __restrict__ out)
+{
+    __shared__ int lds_stack[PTK_MAX_BVH_DEPTH * PTK_BLOCK];
+    const int i = blockIdx.x * PTK_BLOCK + threadIdx.x;
+    if (i >= P.n) return;
+    Rng rng; rng.inc = (hash32(0u ^ 0x9E3779B9u) << 1) | 1u; rng.state = hash32(0u); rng.key = rng.state;
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const v3 p = V(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]), n = V(nrm[i * 3], nrm[i * 3 + 1], nrm[i * 3 + 2]);
+    const v3 diffuse = V(dif[i * 3], dif[i * 3 + 1], dif[i * 3 + 2]);
+    v3 l, dl, di, res = V(0.0f, 0.0f, 0.0f);
+    int light_tri;
+    if (P.num_lights > 0 && sample_direct_light(P, p, n, diffuse, tape[i * 3], tape[i * 3 + 1], tape[i * 3 + 2], l, dl, di, light_tri))
+    {
+        Walk W;
+        W.begin(p, l, P.num_nodes, lds_stack + threadIdx.x);
+        W.occl_tri = light_tri; W.occl_limit = sqrt_ieee(dot(dl, dl)) * 0.9999f;
+        while (!W.done()) walk_step<false, PTK_BLOCK>(P, W, rng, 0u, lds_stack + threadIdx.x, cnt);
+        if (!(W.best.tri != PTK_NOHIT && W.best.tri != W.occl_tri)) res = di;        // :522-526: lit unless something else is closest
+    }
+    out[i * 3] = res.x; out[i * 3 + 1] = res.y; out[i * 3 + 2] = res.z;
+}
+void launch_probe_direct(const ProbeParams& p, const float* pts, const float* nrm, const float* dif, const float* tape, float* out, hipStream_t stream)
+{
+    if (p.n > 0) hipLaunchKernelGGL(probe_direct_kernel, dim3((p.n + PTK_BLOCK - 1) / PTK_BLOCK), dim3(PTK_BLOCK), 0, stream, p, pts, nrm, dif, tape, out);
 }
 
 // Parity probe of the exact-arithmetic helpers the kernels use in place of `1.0f / a` and `sqrtf(x)` (op 0: rcp_ieee,

@@ -63,7 +63,7 @@ SYMBOLS = [
     "ptk_request_exit", "ptk_synchronize", "ptk_last_error", "ptk_accum_device_ptr", "ptk_rgb8_device_ptr",
     "ptk_bind_accum", "ptk_set_stream", "ptk_gather_accum", "ptk_set_option", "ptk_last_render_ms",
     "ptk_last_kernel_ms", "ptk_collect_stats",
-    "ptk_bvh_info", "ptk_bvh_layout", "ptk_upload_timing", "ptk_download_bvh", "ptk_probe_hits", "ptk_probe_primary_dirs", "ptk_probe_math", "ptk_host_alloc", "ptk_host_free",
+    "ptk_bvh_info", "ptk_bvh_layout", "ptk_upload_timing", "ptk_download_bvh", "ptk_probe_hits", "ptk_probe_primary_dirs", "ptk_probe_math", "ptk_probe_direct", "ptk_host_alloc", "ptk_host_free",
     "ptk_packed_floats", "ptk_packed_layout", "ptk_comm_unique_id", "ptk_comm_init", "ptk_comm_destroy",
     "ptk_gather_wait", "ptk_read_gathered", "ptk_gathered_device_ptr", "ptk_probe_pack", "ptk_probe_unpack",
 ]
@@ -123,6 +123,7 @@ def load() -> C.CDLL:
     L.ptk_upload_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.ptk_probe_hits.argtypes = [vp, i32, vp, vp, vp, vp]
     L.ptk_probe_math.argtypes = [vp, i32, i32, vp, vp]
+    L.ptk_probe_direct.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.ptk_probe_primary_dirs.argtypes = [vp, vp]
     _lib = L
     return L
@@ -330,6 +331,14 @@ class Context:
         tri = np.empty(n, np.int32); tuv = np.empty((n, 3), np.float32)
         self._chk(self.L.ptk_probe_hits(self.h, n, ro.ctypes.data, rd.ctypes.data, tri.ctypes.data, tuv.ctypes.data), "ptk_probe_hits")
         return tri, tuv
+
+    def probe_direct(self, p, n, diffuse, tape) -> np.ndarray:
+        """DirectIllumimation at surface points p with normals n, its three draws per point on `tape` ([N, 3] each)."""
+        a = [np.ascontiguousarray(x, np.float32).reshape(-1, 3) for x in (p, n, diffuse, tape)]
+        out = np.empty_like(a[0])
+        self._chk(self.L.ptk_probe_direct(self.h, len(a[0]), a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, out.ctypes.data),
+                  "ptk_probe_direct")
+        return out
 
     def probe_math(self, op: int, x: np.ndarray) -> np.ndarray:
         """The kernels' exact-arithmetic helpers on an array (op 0 rcp, 1 rcp with special cases, 2 sqrt, 3 1/sqrt)."""

@@ -118,6 +118,25 @@ def test_closest_hit_matches_oracle(ctx, oracle_mod):
             assert np.array_equal(tuv[i], v), i
 
 
+def test_direct_illumination_with_tape_matches_the_reference(ctx, oracle_mod):
+    """DirectIllumimation (pathtracer.cpp:505-531) on the GPU at the golden fixture's 300 surface points, the three draws
+    replayed from the REFERENCE's tape: the kernels' light sampling, shadow walk and visibility rule (ptk_probe_direct, the
+    same device functions trace_kernel runs) give the reference's value - bit for bit the oracle's, which tier K pins to
+    the reference within 1e-6 - and the same lit / unlit decision at every point."""
+    z = load_golden("tier_k_scene.npz")
+    arrays = scene_from_golden(z)
+    ctx.upload_scene(arrays)
+    p, n, dif, tape, exp = z["di_p"], z["di_n"], z["di_diffuse"], z["di_tape"], z["di_out"]
+    got = ctx.probe_direct(p, n, dif, tape)
+    o = oracle_mod.Oracle(arrays)
+    want = np.stack([o.direct_illumination_tape(p[i], n[i], dif[i], tape[i]) for i in range(len(p))])
+    o.close()
+    assert np.array_equal(got, want)
+    lit = (exp != 0).any(axis=1)
+    assert np.array_equal((got != 0).any(axis=1), lit) and 0.05 < lit.mean() < 0.95
+    assert np.allclose(got, exp, rtol=1e-6, atol=1e-7)
+
+
 def test_primary_dirs_match_oracle(ctx, oracle_mod):
     z = load_golden("tier_s_opacity.npz")
     arrays = scene_from_golden(z); cam = _cam_from_golden(z)
