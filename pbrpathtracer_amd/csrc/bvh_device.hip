@@ -231,7 +231,7 @@ __device__ __forceinline__ void box_grow(BinBox& b, const uint32_t* w)
 
 // One thread per node of the level: sweep its histograms, close it as a leaf or split it (bvh_build.cpp Builder::build).
 __global__ __launch_bounds__(kThreads) void level_split_kernel(BNode* __restrict__ nodes, const uint32_t* __restrict__ hist, uint32_t* counters, int lvl_start, int lvl_end,
-                                                               int level /* 1-based */, int max_depth, int leaf_max)
+                                                               int level /* 1-based */, int max_depth, int leaf_max, float trav_cost)
 {
     const int id = lvl_start + blockIdx.x * kThreads + threadIdx.x;
     if (id >= lvl_end) return;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kThreads) void level_split_kernel(BNode* __restrict
                 if (ha[k * 7]) box_grow(acc, ha + k * 7);
                 c += (int)ha[k * 7];
                 if (c == 0 || right_cnt[k + 1] == 0) continue;
-                const float cost = 1.0f + (half_area(acc.mn, acc.mx) * (float)c + right_area[k + 1] * (float)right_cnt[k + 1]) / parent_area;
+                const float cost = trav_cost + (half_area(acc.mn, acc.mx) * (float)c + right_area[k + 1] * (float)right_cnt[k + 1]) / parent_area;
                 if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = k; }
             }
         }
@@ -535,6 +535,8 @@ bool build_bvh_device(const float* d_verts, int32_t n, int max_stack, int leaf_m
     out = DeviceBvh();
     if (n < 2 || (int64_t)n >= (1ll << 27)) { if (err) *err = "triangle count outside the device builder's range"; return false; }
     leaf_max = std::min(std::max(leaf_max, 1), 8);
+    float trav_cost = 1.0f;             // SAH: one node visit in units of one triangle test
+    if (const char* e = std::getenv("PTK_TRAV_COST")) if (*e) trav_cost = (float)std::atof(e);      // experiments only
     const auto t0 = std::chrono::steady_clock::now();
     const bool verbose = std::getenv("PTK_BVH_TIMING") != nullptr;      // developer diagnostics: phase times on stderr
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
@@ -585,7 +587,7 @@ bool build_bvh_device(const float* d_verts, int32_t n, int max_stack, int leaf_m
                                    d_boxes, d_node_of, d_bnodes, d_hist, n, ls, count, level);
             else
                 hipLaunchKernelGGL(level_bin_kernel, dim3(blocks_for(n, kThreads)), dim3(kThreads), 0, stream, d_boxes, d_node_of, d_bnodes, d_hist, n, ls, level);
-            hipLaunchKernelGGL(level_split_kernel, dim3(blocks_for(count, kThreads)), dim3(kThreads), 0, stream, d_bnodes, d_hist, d_cnt, ls, lvl_end, level, max_stack, leaf_max);
+            hipLaunchKernelGGL(level_split_kernel, dim3(blocks_for(count, kThreads)), dim3(kThreads), 0, stream, d_bnodes, d_hist, d_cnt, ls, lvl_end, level, max_stack, leaf_max, trav_cost);
             DCHK(hipGetLastError());
             DCHK(hipMemcpyAsync(h_cnt, d_cnt, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             DCHK(hipStreamSynchronize(stream));

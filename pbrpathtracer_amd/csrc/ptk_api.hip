@@ -556,7 +556,9 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
         tmp.p.push_back(d_verts);
         HIPCHK(c, hipMemcpyAsync(d_verts, s->verts, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice, c->stream));
         std::string derr;
-        on_device = build_bvh_device(d_verts, n, PTK_MAX_BVH_DEPTH, 4, c->stream, dbvh, &derr);
+        int leaf_max = 4;
+        if (const char* e = std::getenv("PTK_LEAF_MAX")) if (*e) leaf_max = std::atoi(e);            // experiments only
+        on_device = build_bvh_device(d_verts, n, PTK_MAX_BVH_DEPTH, leaf_max, c->stream, dbvh, &derr);
         if (on_device && dbvh.stack_need > PTK_MAX_BVH_DEPTH) { (void)hipFree(dbvh.d_nodes); (void)hipFree(dbvh.d_order); on_device = false; }
     }
     if (!on_device)
