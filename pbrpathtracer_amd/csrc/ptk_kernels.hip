@@ -109,6 +109,9 @@ __device__ __forceinline__ float rcp_ieee_any(float a)
 #ifndef PTK_NODE_PREFETCH
 #define PTK_NODE_PREFETCH 1
 #endif
+#ifndef PTK_FUSED_START
+#define PTK_FUSED_START 1
+#endif
 #ifndef PTK_SHORT_SQRT
 #define PTK_SHORT_SQRT 1
 #endif
@@ -731,7 +734,15 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                     pix = (lds_item[IT_Y0] + (q >> 3)) * (uint32_t)P.width + lds_item[IT_X0] + (q & 7u);
                     sample_abs = lds_item[IT_SBEGIN] + s_in_chunk;
                     out_idx = lds_item[IT_OUTBASE] + s_in_chunk * 64u + q;
+#if PTK_FUSED_START
+                    // cached camera rays (pinhole, no stochastic opacity): the path starts at its first surface
+                    // interaction, so the lane queues for the SHADE block directly and sets its path up there (depth < 0
+                    // marks it) - one voted block less to wait for per path, and bigger shading batches
+                    st = P.primary_hit ? ST_SHADE : ST_GEN;
+                    depth = -1;
+#else
                     st = ST_GEN;
+#endif
                 }
                 next_unit = min(total_units, next_unit + (uint32_t)__popcll(m_need));
                 m_need = __ballot(st == ST_NEED);
@@ -849,6 +860,25 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
             if (STATS) { const uint32_t nsx = (uint32_t)__popcll(__ballot(st == ST_SHADE)); if (lane == 0) { cnt.shade_execs++; cnt.shade_lanes += nsx; } }
             if (st == ST_SHADE)
             {
+#if PTK_FUSED_START
+                if (depth < 0)
+                {
+                    // a path dealt since the last shade block (see the camera-ray block below for the reasoning)
+                    const uint2 pr = P.pixel_rng[pix];
+                    const float4 c = P.primary_hit[pix], r = P.primary_rd[pix];
+                    rng.inc = pr.y;
+                    rng.state = hash32(P.first_sample + sample_abs + pr.x);
+                    rng.key = rng.state;
+                    rng.state = rng.state * (747796405u * 747796405u) + rng.inc * (747796405u + 1u);
+                    L = V(0.0f, 0.0f, 0.0f); T = V(1.0f, 1.0f, 1.0f);
+                    depth = 0; iter = 0; inside = false; ray = 1;
+                    W.occl_tri = -1;
+                    if (STATS) cnt.started++;
+                    W.ro = camPos0; W.rd = V(r.x, r.y, r.z);
+                    W.best.tri = __float_as_int(c.x); W.best.t = c.y; W.best.u = c.z; W.best.v = c.w;
+                    W.node = NODE_EXIT; W.top = stack; W.tri_left = 0;
+                }
+#endif
                 // ---- one surface interaction of PathTracer::Trace, pathtracer.cpp:551-727 ----
                 const Hit h = W.best;
                 const v3 ro = W.ro, rd = W.rd;
