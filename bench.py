@@ -58,8 +58,8 @@ WORKLOADS = {"C1": "Cornell box (12 tris), 512x512, 4 bounces, 16 spp",
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)          # ~2 s timed at the headline config: long enough for outside samplers to see it
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (default: the config's spp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
