@@ -27,7 +27,7 @@ Prints ONE JSON line on rank 0 (see the driver contract) including
                  workload (N = 1 only): the reference's own OpenMP path as shipped (oracle/_ref, built from
                  /root/reference by __graft_entry__.build()) and the oracle port with a per-path RNG on all cores;
                  `value` is the FASTER of the two (the >= 10x target is judged against it).
-  other_configs  (N = 1, default run) the deep-BVH configs C4 (2 steps) and C5 (1 step) after the timed headline, so the
+  other_configs  (N = 1, default run) the BVH-walk configs C3, C4 (2 steps each) and C5 (1 step) after the timed headline, so the
                  driver's line carries the BVH-walk kernel's Msamples/s and roofline too.
 """
 from __future__ import annotations
@@ -63,7 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (default: the config's spp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the C4 / C5 block after the headline")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C4 / C5 block after the headline")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--exchange-every", type=int, default=8,
                     help="N > 1: gather the accumulator to rank 0 every K steps (and always after the last timed step)")
@@ -466,7 +466,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_other_configs and args.config == "C2" and not args.opts:
         others = {}
-        for name, k in (("C4", 2), ("C5", 1)):
+        for name, k in (("C3", 2), ("C4", 2), ("C5", 1)):
             try:
                 o, _ = measure(name, args, 0, 1, local_rank, k, 1, headline=False)
                 others[name] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": k, "warmup": 1,
