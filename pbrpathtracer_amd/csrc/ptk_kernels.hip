@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 depth = 0; iter = 0; inside = false; ray = 0;
                 W.occl_tri = -1;
                 if (STATS) cnt.started++;
-                if (PTK_GEN_CACHED_FAST && P.primary_hit)
+                if (!PTK_FUSED_START && PTK_GEN_CACHED_FAST && P.primary_hit)      // (fused start: such lanes never come here)
                 {
                     // Pinhole camera, no stochastic opacity: every sample of this pixel shoots the same camera ray, so its
                     // direction and closest hit were computed once (primary_hits_kernel) and the path starts at its first
@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                     v3 rd = normalize(sub(focalPoint, ro));
                     W.begin(ro, rd, P.num_nodes, stack);
                     st = ST_TRAV;
-                    if (P.primary_hit)
+                    if (!PTK_FUSED_START && P.primary_hit)
                     {
                         const float4 c = P.primary_hit[pix];
                         W.best.tri = __float_as_int(c.x); W.best.t = c.y; W.best.u = c.z; W.best.v = c.w;
