@@ -641,6 +641,7 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
         q[4] = v[3]; q[5] = v[4]; q[6] = v[5]; q[7] = m.emissive[0] * m.emissive_intensity;    // pathtracer.cpp:528
         q[8] = v[6]; q[9] = v[7]; q[10] = v[8]; q[11] = m.emissive[1] * m.emissive_intensity;
         q[12] = m.emissive[2] * m.emissive_intensity;
+        q[13] = as_float(m.tex[5] >= 0 ? texmap[m.tex[5]] : -1);          // its opacity texture (the shadow walk tests the light triangle first)
     }
 
     c->upload_ms[1] = ms_since(t_pack);

@@ -235,11 +235,14 @@ struct Walk {
     int* top;                    // this lane's stack top in LDS (== its column's base when empty); unused by the FLAT kernel
     int tri_next, tri_left;      // pending leaf: records [tri_next, tri_next + tri_left) still to test
     Hit best;
-    // occl_tri >= 0 marks a shadow ray towards light triangle occl_tri whose sample lies at distance
-    // ~occl_limit/(1-1e-4): any accepted hit on another triangle nearer than occl_limit decides the
-    // DirectIllumimation test (pathtracer.cpp:522-526) and ends the walk; it is reported as that hit.
+    // occl_tri >= 0 marks a shadow ray towards light triangle occl_tri.  DirectIllumimation's test (pathtracer.cpp:522-526) is
+    // "the closest hit along the ray is the light triangle (or nothing)".  The light triangle is tested FIRST, before the walk
+    // (its record comes with the light sample), so `best` already holds its hit - if the ray hits it at all - and any other
+    // triangle the walk then accepts is, by the closest-hit rule, nearer: it decides the test and ends the walk.  Order
+    // independent by construction.  (Round 1 ended the walk on any hit nearer than 0.9999 x the distance to the light SAMPLE:
+    // wrong when Moeller-Trumbore places a grazing hit on the light triangle itself nearer than that - found by
+    // tools/soak_random_scenes.py, one pixel-sample in 19 of 3000 random scenes.)
     int occl_tri;
-    float occl_limit;
 
     // node: >= 0 interior node to test next; NODE_EXIT nothing left on the node side; any other negative
     // value = a leaf waiting for the triangle queue (tri_next, tri_left) to drain
@@ -314,7 +317,7 @@ __device__ __forceinline__ bool tri_test(const PT& P, Walk& W, float4 t0, float4
     W.best.t = ok ? t : W.best.t;
     W.best.u = ok ? u : W.best.u;
     W.best.v = ok ? v : W.best.v;
-    return ok & (W.occl_tri >= 0) & (tri != W.occl_tri) & (t < W.occl_limit);
+    return ok & (W.occl_tri >= 0) & (tri != W.occl_tri);
 }
 
 // FLAT pass, both rays of a lane against one triangle in PACKED f32: x = the bounce ray (W), y = the shadow ray (WS).
@@ -372,7 +375,7 @@ __device__ __forceinline__ bool tri_test_pair(const PT& P, Walk& W, Walk& WS, co
     }
     W.best.tri = okb ? tri : W.best.tri; W.best.t = okb ? t.x : W.best.t; W.best.u = okb ? u.x : W.best.u; W.best.v = okb ? v.x : W.best.v;
     WS.best.tri = oks ? tri : WS.best.tri; WS.best.t = oks ? t.y : WS.best.t; WS.best.u = oks ? u.y : WS.best.u; WS.best.v = oks ? v.y : WS.best.v;
-    return oks & (tri != WS.occl_tri) & (t.y < WS.occl_limit);
+    return oks & (tri != WS.occl_tri);
 }
 
 // One BVH step of a lane: up to TWO units of work - one triangle of the pending leaf (arm A) AND one
@@ -485,11 +488,11 @@ __device__ __forceinline__ uint32_t pixel_key(uint32_t seed_lo, uint32_t seed_hi
 // DirectIllumimation's sampling half (pathtracer.cpp:494-521, 527-530; SampleTriangle :494-503): picks a light triangle and a
 // point on it from three draws, in the reference's order, and returns false when the surface faces away (:518-520).  Its
 // visibility half (:522-526, closest hit along l is the light) is the shadow walk the caller starts: towards `l`, with
-// occl_tri = light_tri and occl_limit = |dl| * 0.9999.  di is the value DirectIllumimation returns when that walk finds the
+// occl_tri = light_tri, after testing the light triangle itself (lt0..lt2, its record) first.  di is the value DirectIllumimation returns when that walk finds the
 // light (:530).
 template <class PT>
 __device__ __forceinline__ bool sample_direct_light(const PT& P, v3 p, v3 n, v3 diffuse, float u_light, float u_su, float u_sv,
-                                                    v3& l, float& dist, v3& di, int& light_tri)
+                                                    v3& l, float& dist, v3& di, int& light_tri, float4& lt0, float4& lt1, float4& lt2)
 {
     int lightId = (int)floorf(u_light * (float)P.num_lights);
     if (lightId == P.num_lights && lightId > 0) lightId--;
@@ -507,6 +510,11 @@ __device__ __forceinline__ bool sample_direct_light(const PT& P, v3 p, v3 n, v3 
     l = muls(dl, rcp_ieee_any(dist));
     float ndl = dot(neg(n), neg(l));
     light_tri = __float_as_int(l0.w);
+    // the light triangle's own record, as the walk would fetch it: v0, e1 = v2 - v1, e2 = v3 - v1 (the same subtractions the
+    // record packers perform), its index and opacity texture
+    lt0 = make_float4(l0.x, l0.y, l0.z, l1.x - l0.x);
+    lt1 = make_float4(l1.y - l0.y, l1.z - l0.z, l2.x - l0.x, l2.y - l0.y);
+    lt2 = make_float4(l2.z - l0.z, l0.w, l3.y, 0.0f);
     if (!(ndl > 0.0f)) return false;
     v3 lColor = V(l1.w, l2.w, l3.x);
     di = muls(mulv(lColor, diffuse), ndl);      // :530
@@ -674,10 +682,10 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
     // per-lane path state
     Walk W;
     W.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0, stack);
-    W.occl_tri = -1; W.occl_limit = 0.0f;
+    W.occl_tri = -1;
     Walk WS;                        // FLAT only: the shadow ray, tested in the same pass as the bounce ray
     WS.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0, stack);
-    WS.occl_tri = -1; WS.occl_limit = 0.0f;
+    WS.occl_tri = -1;
     v3 L = V(0.0f, 0.0f, 0.0f), T = V(1.0f, 1.0f, 1.0f);
     v3 Tdi = V(0.0f, 0.0f, 0.0f), nextDir = V(0.0f, 0.0f, 1.0f);
     int depth = 0, iter = 0;
@@ -781,7 +789,6 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                     // (ray number `ray`) and the sampled bounce (`ray + 1`), pathtracer.cpp:638 / :724
                     const bool shadow = WS.occl_tri >= 0;
                     const uint32_t bounce_ray = shadow ? ray + 1u : ray;
-                    bool stop = !shadow;
                     RayPair R;
                     R.ox = f2{ W.ro.x, WS.ro.x }; R.oy = f2{ W.ro.y, WS.ro.y }; R.oz = f2{ W.ro.z, WS.ro.z };
                     R.dx = f2{ W.rd.x, WS.rd.x }; R.dy = f2{ W.rd.y, WS.rd.y }; R.dz = f2{ W.rd.z, WS.rd.z };
@@ -790,7 +797,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                         const f4v a0 = ct[k * TRI_F4], a1 = ct[k * TRI_F4 + 1], a2 = ct[k * TRI_F4 + 2];
                         const float4 t0 = make_float4(a0.x, a0.y, a0.z, a0.w), t1 = make_float4(a1.x, a1.y, a1.z, a1.w),
                                      t2 = make_float4(a2.x, a2.y, a2.z, a2.w);
-                        stop |= tri_test_pair<STATS>(P, W, WS, R, !stop, t0, t1, t2, rng, bounce_ray, ray, cnt);
+                        (void)tri_test_pair<STATS>(P, W, WS, R, shadow, t0, t1, t2, rng, bounce_ray, ray, cnt);
                     }
                     if (shadow)
                     {
@@ -1041,6 +1048,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
 
                         L = add(L, mulv(T, muls(emiss, emissI)));      // emiss * emissiveIntensity term
                         v3 next_ro = p, next_rd = dir;
+                        float4 lt0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), lt1 = lt0, lt2 = lt0;
                         if (diffuse_bounce && P.num_lights > 0)
                         {
                             // DirectIllumimation + SampleTriangle, pathtracer.cpp:494-531
@@ -1048,20 +1056,19 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                             v3 l, di;
                             float light_dist;
                             int light_tri;
-                            if (sample_direct_light(P, p, n, diffuse, u_light, u_su, u_sv, l, light_dist, di, light_tri))
+                            if (sample_direct_light(P, p, n, diffuse, u_light, u_su, u_sv, l, light_dist, di, light_tri, lt0, lt1, lt2))
                             {
                                 Tdi = mulv(T, di);
                                 if (FLAT)
                                 {
-                                    // the shadow ray rides along with the bounce ray in the next flat pass
+                                    // the shadow ray rides along with the bounce ray in the next flat pass, which finds its
+                                    // closest hit over ALL triangles (no early end: the pass runs for the bounce ray anyway)
                                     WS.begin(p, l, P.num_nodes, stack);
                                     WS.occl_tri = light_tri;
-                                    WS.occl_limit = light_dist * 0.9999f;
                                 }
                                 else
                                 {
                                     W.occl_tri = light_tri;
-                                    W.occl_limit = light_dist * 0.9999f;
                                     nextDir = dir;
                                     next_rd = l;
                                 }
@@ -1069,6 +1076,8 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                         }
                         T = mulv(T, weight);
                         W.begin(next_ro, next_rd, P.num_nodes, stack);
+                        // a shadow ray meets its light triangle before anything else (see Walk::occl_tri)
+                        if (!FLAT && W.occl_tri >= 0) (void)tri_test<STATS>(P, W, lt0, lt1, lt2, rng, ray, cnt);
                         st = ST_TRAV;
                     }
                 }
@@ -1255,7 +1264,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void primary_hits_kernel(const RenderPar
     v3 focalPoint = add(camPos0, muls(V(d.x, d.y, d.z), P.focal_dist));
     v3 rd = normalize(sub(focalPoint, camPos0));
     Walk W;
-    W.occl_tri = -1; W.occl_limit = 0.0f;
+    W.occl_tri = -1;
     W.begin(camPos0, rd, P.num_nodes, lds_stack + threadIdx.x);
     while (!W.done()) walk_step<false, PTK_BLOCK>(P, W, rng, 0u, lds_stack + threadIdx.x, cnt);
     out[i] = make_float4(__int_as_float(W.best.tri), W.best.t, W.best.u, W.best.v);
@@ -1273,7 +1282,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_hits_kernel(const ProbeParams
     v3 ro = V(P.ro[i * 3], P.ro[i * 3 + 1], P.ro[i * 3 + 2]);
     v3 rd = V(P.rd[i * 3], P.rd[i * 3 + 1], P.rd[i * 3 + 2]);
     Walk W;
-    W.occl_tri = -1; W.occl_limit = 0.0f;
+    W.occl_tri = -1;
     W.begin(ro, rd, P.num_nodes, lds_stack + threadIdx.x);
     while (!W.done()) walk_step<false, PTK_BLOCK>(P, W, rng, 0u, lds_stack + threadIdx.x, cnt);
     bool hit = W.best.tri != PTK_NOHIT;
@@ -1296,11 +1305,13 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_direct_kernel(const ProbePara
     v3 l, di, res = V(0.0f, 0.0f, 0.0f);
     float light_dist;
     int light_tri;
-    if (P.num_lights > 0 && sample_direct_light(P, p, n, diffuse, tape[i * 3], tape[i * 3 + 1], tape[i * 3 + 2], l, light_dist, di, light_tri))
+    float4 lt0, lt1, lt2;
+    if (P.num_lights > 0 && sample_direct_light(P, p, n, diffuse, tape[i * 3], tape[i * 3 + 1], tape[i * 3 + 2], l, light_dist, di, light_tri, lt0, lt1, lt2))
     {
         Walk W;
         W.begin(p, l, P.num_nodes, lds_stack + threadIdx.x);
-        W.occl_tri = light_tri; W.occl_limit = light_dist * 0.9999f;
+        W.occl_tri = light_tri;
+        (void)tri_test<false>(P, W, lt0, lt1, lt2, rng, 0u, cnt);
         while (!W.done()) walk_step<false, PTK_BLOCK>(P, W, rng, 0u, lds_stack + threadIdx.x, cnt);
         if (!(W.best.tri != PTK_NOHIT && W.best.tri != W.occl_tri)) res = di;        // :522-526: lit unless something else is closest
     }
