@@ -112,6 +112,9 @@ __device__ __forceinline__ float rcp_ieee_any(float a)
 #ifndef PTK_FUSED_START
 #define PTK_FUSED_START 1
 #endif
+#ifndef PTK_ROBUST_BOXES
+#define PTK_ROBUST_BOXES 1
+#endif
 #ifndef PTK_SHORT_SQRT
 #define PTK_SHORT_SQRT 1
 #endif
@@ -419,6 +422,19 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
         // multiply-adds and approximate reciprocals are fine here; the grid boxes enclose the padded boxes)
         const float Ax = q0.w * W.inv.x, Ay = q1.x * W.inv.y, Az = q1.y * W.inv.z;
         const float Bx = (q0.x - W.ro.x) * W.inv.x, By = (q0.y - W.ro.y) * W.inv.y, Bz = (q0.z - W.ro.z) * W.inv.z;
+#if PTK_ROBUST_BOXES
+        // CONSERVATIVE for every ray, however far its origin: t = fma(q, A, B) is the sum of two possibly large terms, so its
+        // error is absolute - at most 2^-22 (|B| + 255 |A|) from the roundings of origin - ro, the two products, the 1-ulp
+        // reciprocal and the fma - i.e. a position error of ~6e-8 x the distance between the ray's origin and the node, which
+        // exceeds an 8-bit grid step once that distance is > 65 000 node extents (and Moeller-Trumbore's own decisions carry
+        // the same uncertainty, so no padding of the tree can stand in for it).  Near planes are taken that much (x 2) too
+        // early and far planes too late; found by tools/soak_bvh.py: two clusters of 1e-3 at +-1e3 gave tree-dependent hits.
+        const float sx = __builtin_fmaf(fabsf(Ax), 0x1p-13f, fabsf(Bx) * 0x1p-21f), sy = __builtin_fmaf(fabsf(Ay), 0x1p-13f, fabsf(By) * 0x1p-21f),
+                    sz = __builtin_fmaf(fabsf(Az), 0x1p-13f, fabsf(Bz) * 0x1p-21f);
+        const float Bnx = Bx - sx, Bny = By - sy, Bnz = Bz - sz, Bfx = Bx + sx, Bfy = By + sy, Bfz = Bz + sz;
+#else
+        const float Bnx = Bx, Bny = By, Bnz = Bz, Bfx = Bx, Bfy = By, Bfz = Bz;
+#endif
         // the ray enters a slab through the low plane when it travels in +axis, through the high plane otherwise:
         // pick the near / far plane bytes of all four children at once by the sign of the direction
         const uint32_t mx = (uint32_t)(__float_as_int(W.inv.x) >> 31), my = (uint32_t)(__float_as_int(W.inv.y) >> 31),
@@ -429,18 +445,29 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
         const uint32_t ny = (hiy & my) | (loy & ~my), fy = (loy & my) | (hiy & ~my);
         const uint32_t nz = (hiz & mz) | (loz & ~mz), fz = (loz & mz) | (hiz & ~mz);
         const int link0 = __float_as_int(q1.z), link1 = __float_as_int(q1.w), link2 = __float_as_int(q2.x), link3 = __float_as_int(q2.y);
+#if PTK_ROBUST_BOXES
+        // ... and a node is only culled against the closest hit so far when it lies beyond it by more than Moeller-Trumbore's
+        // own error in t (relative ~1e-7 / cos of the incidence angle: which of two triangles 1e-6 apart is "closest" is
+        // decided by that arithmetic, not by geometry - the second half of the same soak finding)
+        const float tmax = W.best.t * 1.0000153f;
+#else
         const float tmax = W.best.t;
+#endif
         int key[4];
         bool hit[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
         {
-            const float tnx = __builtin_fmaf((float)((nx >> (8 * k)) & 255u), Ax, Bx), tfx = __builtin_fmaf((float)((fx >> (8 * k)) & 255u), Ax, Bx);
-            const float tny = __builtin_fmaf((float)((ny >> (8 * k)) & 255u), Ay, By), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 255u), Ay, By);
-            const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 255u), Az, Bz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 255u), Az, Bz);
+            const float tnx = __builtin_fmaf((float)((nx >> (8 * k)) & 255u), Ax, Bnx), tfx = __builtin_fmaf((float)((fx >> (8 * k)) & 255u), Ax, Bfx);
+            const float tny = __builtin_fmaf((float)((ny >> (8 * k)) & 255u), Ay, Bny), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 255u), Ay, Bfy);
+            const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 255u), Az, Bnz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 255u), Az, Bfz);
             // NaNs (0 * inf for axis-parallel rays) drop out of min3 / max3: that axis then does not constrain - conservative
             const float tn = fmaxf(fmaxf(tnx, tny), tnz), tf = fminf(fminf(tfx, tfy), tfz);
+#if PTK_ROBUST_BOXES
+            hit[k] = (tn <= tf) & (tf >= 0.0f) & (tn <= tmax);
+#else
             hit[k] = (tn <= tf * 1.000001f) & (tf >= 0.0f) & (tn <= tmax);
+#endif
             // order key: the entry distance with the slot in its low bits (negative distances - origin inside - sort first)
             key[k] = hit[k] ? ((__float_as_int(tn) & ~3) | k) : 0x7fffffff;
         }

@@ -104,3 +104,35 @@ def test_device_build_renders_bit_identically_and_is_faster_at_1M(tmp_path):
     print("device: load %.3f s %s, node visits / sample %.2f, triangle tests %.2f" % out[1][1:])
     assert out[1][2]["bvh_ms"] < out[0][2]["bvh_ms"]
     assert out[1][3] <= 1.15 * out[0][3]
+
+
+@pytest.mark.parametrize("seed", [15, 295, 215])
+def test_far_origins_and_tiny_nodes_give_tree_independent_hits(ctx, oracle_mod, seed):
+    """Two clusters of 1e-3 at +-1e3, rays from up to 3000 units away aimed at 0.02-sized triangles (tools/soak_bvh.py, the
+    cases that failed before): the slab distances' absolute error (~6e-8 x the distance between ray origin and node) exceeds
+    the 8-bit grid step of the deep nodes, and Moeller-Trumbore's own error in t decides which of two nearly equidistant
+    triangles is the closest.  The box test carries both as explicit slack (walk_step), so the host-built tree, the
+    device-built tree and the oracle's brute-force loop over all triangles agree on every ray."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([4096, 5000, 12345, 40000]))
+    c = rng.uniform(-1, 1, (n, 1, 3))
+    c = c * 1e-3 + np.where(rng.uniform(0, 1, (n, 1, 1)) < 0.5, -1e3, 1e3)
+    verts = (c + 0.02 * rng.uniform(-1, 1, (n, 3, 3))).astype(np.float32).reshape(n, 9)
+    arrays = _scene(verts)
+    ext = float(np.abs(verts).max())
+    ro = (rng.uniform(-1.5, 1.5, (3000, 3)) * ext).astype(np.float32)
+    tgt = verts.reshape(n, 3, 3)[rng.integers(0, n, 3000)].mean(axis=1)
+    rd = tgt - ro; rd /= np.maximum(np.linalg.norm(rd, axis=1, keepdims=True), 1e-30); rd = rd.astype(np.float32)
+    rd[::40, 1] = 0.0
+    ctx.set_option("device_build", 0); ctx.upload_scene(arrays); tri_h, tuv_h = ctx.probe_hits(ro, rd)
+    check_bvh(*ctx.download_bvh(), verts)
+    ctx.set_option("device_build", 1); ctx.upload_scene(arrays); tri_d, tuv_d = ctx.probe_hits(ro, rd)
+    check_bvh(*ctx.download_bvh(), verts)
+    assert (tri_h >= 0).mean() > 0.9
+    assert np.array_equal(tri_h, tri_d) and np.array_equal(tuv_h, tuv_d)
+    o = oracle_mod.Oracle(arrays)
+    for j in range(0, 3000, 7):
+        h, t, v = o.hit(ro[j], rd[j], brute=True)
+        assert (t if h else -1) == tri_d[j], j
+        if h: assert np.array_equal(v, tuv_d[j]), j
+    o.close()

@@ -9,6 +9,31 @@ from pbrpathtracer_amd import ptk
 from oracle import oracle_binding as OB
 from test_gpu_random_scenes import random_scene
 
+def vary(arrays, cam, variant, seed):
+    """stress variants on top of the generator: exact duplicates (ties on t), grid-snapped geometry (coplanar faces, shared
+    edges, degenerate triangles), tiny and huge scales"""
+    rng = np.random.default_rng(seed * 7 + variant)
+    a = {k: v.copy() for k, v in arrays.items()}
+    cam = dict(cam)
+    per_tri = ("verts", "normals", "uvs", "tbn", "smoothing", "material")
+    if variant == 1:
+        n = len(a["verts"]); pick = rng.integers(0, n, max(1, n // 3))
+        for k in per_tri: a[k] = np.concatenate([a[k], a[k][pick]])
+        a["material"][n:] = rng.integers(0, len(a["materials"]), len(pick))
+        perm = rng.permutation(len(a["verts"]))
+        for k in per_tri: a[k] = np.ascontiguousarray(a[k][perm])
+        m = a["materials"]; mat = a["material"]
+        a["lights"] = np.nonzero((m["emissive"][mat] * m["emissive_intensity"][mat, None]).sum(axis=1) > 0)[0].astype(np.int32)
+    elif variant == 2:
+        a["verts"] = (np.round(a["verts"] * 4.0) / 4.0).astype(np.float32)
+    elif variant in (3, 4):
+        sc = np.float32(0.03 if variant == 3 else 1e3)
+        a["verts"] = (a["verts"] * sc).astype(np.float32)
+        cam["pos"] = (cam["pos"] * sc).astype(np.float32); cam["focal"] = float(cam["focal"] * sc); cam["focal_dist"] = float(cam["focal_dist"] * sc)
+        cam["aperture"] = float(cam["aperture"] * sc)
+    return a, cam
+
+
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 ctx = ptk.Context(0)
@@ -19,11 +44,16 @@ for k in range(count):
     seed = first + k
     n = sizes[k % len(sizes)]
     arrays, cam = random_scene(seed, n, bool(k & 1))
+    variant = (seed // 10) % 5
+    arrays, cam = vary(arrays, cam, variant, seed)
     W, H, D, spp = 48 + (seed % 3) * 8, 32 + (seed % 5) * 3, 3 + seed % 6, 4
     o = OB.Oracle(arrays)
     ocam = OB.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
     ref, ref8 = o.render(ocam, W, H, D, 0, spp, seed)
     o.close()
+    if not np.isfinite(ref).all():
+        print(f"seed {seed}: oracle image not finite (variant {variant}): skipped", flush=True)
+        continue
     for dev in (0, 1):
         ctx.set_option("device_build", dev)
         ctx.upload_scene(arrays); ctx.set_camera(**cam); ctx.set_frame(W, H, D); ctx.set_tile(0, 1); ctx.reset()
@@ -31,7 +61,7 @@ for k in range(count):
         ok = np.array_equal(ref, ctx.read_accum()) and np.array_equal(ref8, ctx.resolve_rgb8())
         if not ok:
             bad += 1
-            print(f"MISMATCH seed {seed} n {n} device_build {dev}", flush=True)
-    print(f"seed {seed}: {n} triangles {W}x{H} depth {D} ok, lit {(ref != 0).any(axis=2).mean():.2f}  [{time.time() - t0:.0f} s]", flush=True)
+            print(f"MISMATCH seed {seed} n {n} variant {variant} device_build {dev}", flush=True)
+    print(f"seed {seed} variant {variant}: {n} triangles {W}x{H} depth {D} ok, lit {(ref != 0).any(axis=2).mean():.2f}  [{time.time() - t0:.0f} s]", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
