@@ -20,7 +20,7 @@ for k in range(count):
     world = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 33, 64]))
     ctx.set_frame(W, H, 2); ctx.set_tile(0, 1); ctx.reset()
     accum = rng.uniform(-1, 1, (H, W, 3)).astype(np.float32)
-    ctx.write_accum(accum)
+    ctx.write_accum(accum, 1)
     flat = accum.reshape(-1)
     packed = []; ok = True; covered = np.zeros(W * H * 3, np.int32)
     for r in range(world):
