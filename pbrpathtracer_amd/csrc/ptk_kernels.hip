@@ -519,7 +519,7 @@ __device__ __forceinline__ uint32_t pixel_key(uint32_t seed_lo, uint32_t seed_hi
 // light (:530).
 template <class PT>
 __device__ __forceinline__ bool sample_direct_light(const PT& P, v3 p, v3 n, v3 diffuse, float u_light, float u_su, float u_sv,
-                                                    v3& l, float& dist, v3& di, int& light_tri, float4& lt0, float4& lt1, float4& lt2)
+                                                    v3& l, v3& di, int& light_tri, float4& lt0, float4& lt1, float4& lt2)
 {
     int lightId = (int)floorf(u_light * (float)P.num_lights);
     if (lightId == P.num_lights && lightId > 0) lightId--;
@@ -531,10 +531,7 @@ __device__ __forceinline__ bool sample_direct_light(const PT& P, v3 p, v3 n, v3 
     v3 vLight = add(add(muls(V(l0.x, l0.y, l0.z), w0), muls(V(l1.x, l1.y, l1.z), w1)),
                     muls(V(l2.x, l2.y, l2.z), w2));
     const v3 dl = sub(vLight, p);
-    // l = normalize(dl) spelled out, so that the length - the shadow ray's reach - is computed once (normalize's own
-    // squared length is this very expression, and its root would not be merged with a second one across the helper's branch)
-    dist = sqrt_ieee(dl.x * dl.x + dl.y * dl.y + dl.z * dl.z);
-    l = muls(dl, rcp_ieee_any(dist));
+    l = normalize(dl);
     float ndl = dot(neg(n), neg(l));
     light_tri = __float_as_int(l0.w);
     // the light triangle's own record, as the walk would fetch it: v0, e1 = v2 - v1, e2 = v3 - v1 (the same subtractions the
@@ -1081,9 +1078,8 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                             // DirectIllumimation + SampleTriangle, pathtracer.cpp:494-531
                             const float u_light = rng.next(), u_su = rng.next(), u_sv = rng.next();
                             v3 l, di;
-                            float light_dist;
                             int light_tri;
-                            if (sample_direct_light(P, p, n, diffuse, u_light, u_su, u_sv, l, light_dist, di, light_tri, lt0, lt1, lt2))
+                            if (sample_direct_light(P, p, n, diffuse, u_light, u_su, u_sv, l, di, light_tri, lt0, lt1, lt2))
                             {
                                 Tdi = mulv(T, di);
                                 if (FLAT)
@@ -1330,10 +1326,9 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_direct_kernel(const ProbePara
     const v3 p = V(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]), n = V(nrm[i * 3], nrm[i * 3 + 1], nrm[i * 3 + 2]);
     const v3 diffuse = V(dif[i * 3], dif[i * 3 + 1], dif[i * 3 + 2]);
     v3 l, di, res = V(0.0f, 0.0f, 0.0f);
-    float light_dist;
     int light_tri;
     float4 lt0, lt1, lt2;
-    if (P.num_lights > 0 && sample_direct_light(P, p, n, diffuse, tape[i * 3], tape[i * 3 + 1], tape[i * 3 + 2], l, light_dist, di, light_tri, lt0, lt1, lt2))
+    if (P.num_lights > 0 && sample_direct_light(P, p, n, diffuse, tape[i * 3], tape[i * 3 + 1], tape[i * 3 + 2], l, di, light_tri, lt0, lt1, lt2))
     {
         Walk W;
         W.begin(p, l, P.num_nodes, lds_stack + threadIdx.x);
