@@ -238,7 +238,10 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     p.samples = c->d_samples;
     // shallow trees give short, uniform walks: waiting for stragglers is cheap and re-synchronises the
     // wave (lambda 25); deep trees have heavy-tailed walks: shade small batches early (lambda 5)
-    p.shade_thr = c->opt_shade_thr > 0 ? c->opt_shade_thr : (c->bvh_depth <= 4 ? 200 : 40);
+    // lambda of the ski-rental rule = cost(shade block) / cost(one walk iteration), in eighths: a walk iteration of a tree far
+    // larger than the L2 waits for memory and costs more, so the shade block is run for smaller batches there (measured
+    // optimum: ~72 for 10-20 k nodes, ~46 for 370 k nodes; flat within 1 % around either)
+    p.shade_thr = c->opt_shade_thr > 0 ? c->opt_shade_thr : (c->bvh_depth <= 4 ? 200 : (c->num_nodes >= 131072 ? 46 : 68));
     p.gen_thr = c->opt_gen_thr;
     p.tri_thr = c->opt_tri_thr;
     p.max_batch = c->opt_max_batch;
