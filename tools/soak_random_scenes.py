@@ -47,6 +47,7 @@ for k in range(count):
     variant = (seed // 10) % 5
     arrays, cam = vary(arrays, cam, variant, seed)
     W, H, D, spp = 48 + (seed % 3) * 8, 32 + (seed % 5) * 3, 3 + seed % 6, 4
+    if os.environ.get("SOAK_DEEP"): D, spp = 6 + seed % 7, 10          # long paths: glass chains, roulette, many light samples
     o = OB.Oracle(arrays)
     ocam = OB.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
     ref, ref8 = o.render(ocam, W, H, D, 0, spp, seed)
