@@ -22,15 +22,20 @@
 //     lanes that block would leave idle.  Divergent blocks therefore run with full-ish EXEC masks instead of
 //     once per ray.  Scenes of <= 16 triangles skip the hierarchy (FLAT: scalar triangle loads, shadow and
 //     bounce ray in one pass).
-//   * Closest hit: BVH2 with both child boxes in the 64-byte parent record (left/right planes
-//     interleaved -> packed-f32 slab arithmetic), ordered descent with t-max culling, per-lane stack
-//     in LDS laid out [level][thread] (conflict-free ds_read/write_b32).  Result = min over accepted
-//     triangles with an order-independent tie rule, so it does not depend on the tree (the
-//     reference's own tree is random, mesh.cpp:171-172).  Box tests are acceleration only (any
-//     conservative test gives the same hit), so they use v_rcp and packed math; everything that
-//     reaches the image (Moeller-Trumbore, shading) is IEEE and in the reference's order.
-//   * Shadow rays keep the reference's closest-hit + identity test (pathtracer.cpp:522-526) but stop
-//     as soon as an accepted occluder strictly nearer than the light sample is found (same outcome).
+//   * Closest hit: 4-wide BVH, one 64-byte record per node holding the four child boxes quantised OUTWARD to 8 bits on
+//     the node's own grid (t = fma(q, A, B) per plane), nearest child first, the others on a per-lane stack in LDS laid
+//     out [level][lane] (conflict-free ds_read/write_b32); the node record is requested before the triangle arm runs.
+//     Result = min over accepted triangles with an order-independent tie rule, so it does not depend on the tree (the
+//     reference's own tree is random, mesh.cpp:171-172).  Box tests are acceleration only, so they use v_rcp and fused
+//     multiply-adds - but they are CONSERVATIVE for any ray origin and triangle size (explicit slack for the slab
+//     arithmetic's absolute error and for Moeller-Trumbore's own error in t, see walk_step); everything that reaches the
+//     image (Moeller-Trumbore, shading, samplers) is IEEE and in the reference's order, with 1/x and sqrt as short
+//     sequences proven bit-identical by enumeration (rcp_ieee, sqrt_ieee).
+//   * Shadow rays keep the reference's closest-hit + identity test (pathtracer.cpp:522-526): the light triangle is
+//     tested first (its record comes with the light sample), then any hit the closest-hit rule accepts is nearer and
+//     ends the walk (Walk::occl_tri).
+//   * Pinhole cameras without opacity textures: the camera ray's hit is cached per pixel, pixels whose camera ray
+//     misses are never traced, and a new path starts directly in the SHADE block (PTK_FUSED_START).
 //   * RNG: PCG-RXS-M-XS-32 per path, keyed on (seed, pixel, sample) - never on lane/block/GPU.
 //
 // Float arithmetic is written operation by operation in the reference's order and this file is
