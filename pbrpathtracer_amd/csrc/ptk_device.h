@@ -10,8 +10,8 @@
 
 namespace ptk {
 
-// BVH4 node, 64 B = one dependent fetch per FOUR child boxes (the walk is bound by the rate at which the vector memory
-// pipeline gathers records, profiles/r02/gather_ceiling.json, so bytes and records per ray are what counts).
+// BVH4 node, 64 B = one dependent fetch per FOUR child boxes (round 1's binary walk ran at the rate at which the vector
+// memory pipeline gathers records, profiles/r02/gather_ceiling.json: records per ray are what counted).
 // Child boxes are quantised outward to 8 bits on a per-node grid: plane = origin + q * scale.
 //   q0 = (origin.xyz, scale.x)   q1 = (scale.yz, bits link0, bits link1)
 //   q2 = (bits link2, bits link3, bits lo.x, bits lo.y)   q3 = (bits lo.z, bits hi.x, bits hi.y, bits hi.z)
@@ -36,8 +36,9 @@ constexpr int SHADE_F4 = 7;
 //   m3 = (reflectiveness, translucency, ior, rr_prob)  m4 = bits tex[0..3]  m5 = bits (tex[4], tex[5], any_tex, 0)
 constexpr int MAT_F4 = 6;
 
-// Light record, 64 B:  l0 = (v1.xyz, bits tri)  l1 = (v2.xyz, c.r)  l2 = (v3.xyz, c.g)  l3 = (c.b, 0, 0, 0)
-// with c = emissive * emissiveIntensity of the light's material (pathtracer.cpp:528)
+// Light record, 64 B:  l0 = (v1.xyz, bits tri)  l1 = (v2.xyz, c.r)  l2 = (v3.xyz, c.g)  l3 = (c.b, bits opacity_tex, 0, 0)
+// with c = emissive * emissiveIntensity of the light's material (pathtracer.cpp:528); tri and opacity_tex let the shadow walk
+// rebuild the light triangle's own intersection record (v1, v2 - v1, v3 - v1: the record packers' subtractions) and test it first
 constexpr int LIGHT_F4 = 4;
 
 // Radiance samples travel from the trace kernel to the accumulate kernel through HBM:
