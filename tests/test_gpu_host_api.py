@@ -253,6 +253,29 @@ def test_full_size_spot_check_against_oracle(tmp_path, oracle_mod, cfg, world):
     pt.close()
 
 
+def test_headline_config_whole_frame_at_full_sample_count(tmp_path, oracle_mod):
+    """bench.py's headline workload - C2, 1280x720, 8 bounces, 256 spp: 236 M samples - EVERY pixel against the oracle, float
+    accumulator and RGB8, bit for bit (the oracle takes ~10 s of the GPU box's host cores for it)."""
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
+    pts, scene, spp = S.build_config("C2", str(tmp_path))
+    pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(33)
+    cam = camera_from_scene(scene)
+    pt.SetCameraAperture(0.0); cam["aperture"] = 0.0           # as bench.py does (the .pts carries F = 1e9)
+    W, H = pt.GetResolution(); Dp = pt.GetTraceDepth()
+    out = np.zeros((H, W, 3), np.uint8); pt.SetOutImage(out)
+    pt.RenderFrames(spp)
+    assert pt.LastError() == "" and pt.GetSamples() == spp == 256 and (W, H, Dp) == (1280, 720, 8)
+    got = pt.ReadAccumulation()
+    o = oracle_mod.Oracle(pt.StagedScene())
+    ocam = oracle_mod.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+    ref, ref8 = o.render(ocam, W, H, Dp, 0, spp, 33)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(out, ref8)
+    assert (ref != 0).any(axis=2).mean() > 0.15                 # (the box covers about a fifth of this camera's frame)
+    pt.close()
+
+
 def test_c5_tile_split_over_8_ranks_on_one_gpu(tmp_path, oracle_mod):
     """BASELINE configs[4]'s shape - the 1 M-triangle frame tile-split over 8 ranks and gathered - with this one GPU playing
     every rank in turn: each rank's share is rendered (ptk_set_tile), packed by the exchange's pack kernel, and the eight
