@@ -566,6 +566,7 @@ ptk_ctx* PathTracer::Context() { m->ensure_ctx(); return m->ctx; }
 const ptk_scene_desc* PathTracer::StagedScene()
 {
     flatten_scene(m->triangles, m->objects, m->flat);
+    if (m->scene_uploaded) m->flat.lights = m->built_lights;         // mLights is BuildBVH's, whatever was edited since (pathtracer.cpp:267-273)
     m->flat_desc = m->flat.desc();
     return &m->flat_desc;
 }

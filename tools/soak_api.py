@@ -1,0 +1,71 @@
+"""GPU box, one-off: random sequences of host-API calls on the drop-in PathTracer (camera, projection, lens, resolution, trace
+depth, seed, material edits after BuildBVH, sample batching, a second tracer on the same GPU) - after every stage the
+accumulator must be the oracle's for the state the calls left behind.  python tools/soak_api.py [first_seed] [count]"""
+import os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa: F401
+from pbrpathtracer_amd import scenes as S
+from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
+from oracle import oracle_binding as OB
+OB.build()
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+tmp = tempfile.mkdtemp()
+cfgs = [("C1", dict(width=96, height=64)), ("C4", dict(width=96, height=64, grid=14)), ("C3", dict(width=80, height=56))]
+built = {}
+for name, kw in cfgs:
+    d = os.path.join(tmp, name); os.makedirs(d)
+    built[name] = S.build_config(name, d, **kw)
+bad = 0; t0 = time.time(); stages = 0
+for k in range(count):
+    seed = first + k
+    rng = np.random.default_rng(seed)
+    name = cfgs[k % len(cfgs)][0]
+    pts, scene, _ = built[name]
+    pt = PathTracer(0); pt.LoadSceneFile(pts)
+    other = PathTracer(0); other.LoadSceneFile(built["C1"][0])
+    cam = camera_from_scene(scene)
+    st = dict(W=pt.GetResolution()[0], H=pt.GetResolution()[1], D=pt.GetTraceDepth(), seed=0)
+    for stage in range(int(rng.integers(3, 8))):
+        op = int(rng.integers(0, 8))
+        if op == 0:
+            cam["pos"] = (np.asarray(cam["pos"], np.float32) + rng.uniform(-0.3, 0.3, 3).astype(np.float32)); pt.SetCamera(cam["pos"], cam["dir"], cam["up"])
+        elif op == 1:
+            cam["aperture"] = float(rng.choice([0.0, 0.03])); pt.SetCameraAperture(cam["aperture"])
+        elif op == 2:
+            st["W"], st["H"] = int(rng.integers(8, 130)), int(rng.integers(8, 90)); pt.SetResolution((st["W"], st["H"]))
+        elif op == 3:
+            st["D"] = int(rng.integers(1, 9)); pt.SetTraceDepth(st["D"])
+        elif op == 4:
+            st["seed"] = int(rng.integers(0, 1 << 30)); pt.SetSeed(st["seed"])
+        elif op == 5:
+            cam["fovy"] = float(rng.uniform(30, 80)); pt.SetProjection(cam["focal"], cam["fovy"])
+        elif op == 6:
+            m = np.array([int(rng.integers(0, 2)), *rng.uniform(0.1, 0.9, 3), *rng.uniform(0.2, 1, 3), *(rng.uniform(0, 1, 3) * (rng.uniform() < 0.3)),
+                          float(rng.uniform(1, 5)), float(rng.choice([0, 0.4, 1])), float(rng.choice([0, 0.5, 1])), float(rng.choice([0, 1])), 1.5], np.float32)
+            objs = pt.GetLoadedObjects()
+            ob = int(rng.integers(0, len(objs)))
+            pt.SetMaterial(ob, int(rng.integers(0, max(1, objs[ob]))), m)
+        else:
+            cam["focal_dist"] = float(cam["focal_dist"] * rng.uniform(0.8, 1.2)); pt.SetCameraFocalDist(cam["focal_dist"])
+        pt.ResetImage()
+        total = int(rng.integers(1, 9)); done = 0
+        while done < total:
+            b = int(rng.integers(1, total - done + 1)); pt.RenderFrames(b); done += b
+            if rng.uniform() < 0.3: other.RenderFrames(1)            # another tracer on the same GPU in between
+        err = pt.LastError()
+        got = pt.ReadAccumulation()
+        o = OB.Oracle(pt.StagedScene())
+        ocam = OB.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+        ref, _ = o.render(ocam, st["W"], st["H"], st["D"], 0, total, st["seed"], want_rgb8=False)
+        o.close()
+        stages += 1
+        if err or got.shape != ref.shape or not np.array_equal(got, ref):
+            bad += 1
+            print(f"MISMATCH seed {seed} {name} stage {stage} op {op} state {st} aperture {cam['aperture']} err '{err}'", flush=True)
+    pt.close(); other.close()
+    if k % 20 == 0: print(f"seed {seed} done [{time.time() - t0:.0f} s]", flush=True)
+print("stages", stages, "mismatches:", bad)
+sys.exit(1 if bad else 0)
