@@ -203,7 +203,8 @@ int ptk_probe_unpack(ptk_ctx* ctx, int world, const float* host_packed /* all ra
  * budget of the sample buffer between the trace and accumulate kernels (default 4 GiB);
  * "shade_threshold" / "gen_threshold" = scheduling lambdas of the wave state machine in eighths
  * (cost of the shading / camera-ray block relative to one BVH walk step; defaults: shading 200 for
- * trees of depth <= 8 else 40 (0 = this automatic choice), camera rays 16); "tri_threshold" = the
+ * trees of depth <= 4, else 68, or 46 for trees of 131 072 nodes and more (0 = this automatic choice), camera rays 16);
+ * "tri_threshold" = the
  * triangle arm of the BVH walk runs once the lanes holding a leaf reach this many eighths of the lanes
  * that can still walk (default 4; 0 = every iteration); "device_build" = 0/1 (default 1): build the BVH of scenes of >= 4096 triangles on the GPU;
  * "primary_cache" = 0/1, reuse the camera ray's closest
