@@ -37,7 +37,7 @@ def vary(arrays, cam, variant, seed):
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 ctx = ptk.Context(0)
-sizes = [5, 12, 16, 17, 64, 500, 3000, 4096, 5000, 20000]
+sizes = [int(x) for x in os.environ["SOAK_SIZES"].split(",")] if os.environ.get("SOAK_SIZES") else [5, 12, 16, 17, 64, 500, 3000, 4096, 5000, 20000]
 bad = 0
 t0 = time.time()
 for k in range(count):
