@@ -95,6 +95,7 @@ struct ptk_ctx {
     bool inputs_dirty = true;                    // scene / camera tables were (re)written on the context's stream since ev_inputs
     unsigned pass_counter = 0;
     int opt_overlap = 1;
+    int opt_contract = 0;                        // 0: bit-exact kernels; 1: -ffp-contract=fast build; 2: ... with 1-ulp hardware rcp / sqrt
     int opt_chunk = 0;                           // samples per work item; 0 = automatic (8, or 4 for small shares)
     int num_cus = 256;
     int opt_generations = 0;                     // 0 automatic: 1 on a single GPU, 2 when the frame is split over ranks
@@ -384,7 +385,9 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         const int pi = c->last_passes < ptk_ctx::kMaxTimedPasses ? c->last_passes : -1;
         if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][0], tstream));
         p.queues = overlap ? c->d_queues2[b] : c->d_queues;
-        launch_trace(p, tiles * 4, c->resident_waves, tstream, stats);
+        if (c->opt_contract == 1 && !stats) fma::launch_trace(p, tiles * 4, c->resident_waves, tstream, false);
+        else if (c->opt_contract == 2 && !stats) fast::launch_trace(p, tiles * 4, c->resident_waves, tstream, false);
+        else launch_trace(p, tiles * 4, c->resident_waves, tstream, stats);
         HIPCHK(c, hipGetLastError());
         if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][1], tstream));
         if (overlap)
@@ -1216,6 +1219,12 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     if (!std::strcmp(name, "overlap"))
     {
         c->opt_overlap = value != 0.0 ? 1 : 0;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "contract"))
+    {
+        if (!(value == 0.0 || value == 1.0 || value == 2.0)) return fail(c, PTK_ERR_BAD_ARG, "contract must be 0 (bit-exact), 1 (fused multiply-adds) or 2 (... and 1-ulp reciprocal / square root)");
+        c->opt_contract = (int)value;
         return PTK_OK;
     }
     if (!std::strcmp(name, "generations"))

@@ -120,6 +120,10 @@ struct ProbeParams {
 };
 
 void launch_trace(const RenderParams& p, int num_subtiles, int resident_waves, hipStream_t stream, bool stats);
+// the same trace kernels from the second and third builds of ptk_kernels.hip (-ffp-contract=fast; `fast` also with the
+// hardware's 1-ulp reciprocal / square root): the "contract" option, results within tolerance instead of bit-exact
+namespace fma { void launch_trace(const RenderParams& p, int num_subtiles, int resident_waves, hipStream_t stream, bool stats); }
+namespace fast { void launch_trace(const RenderParams& p, int num_subtiles, int resident_waves, hipStream_t stream, bool stats); }
 void launch_pixel_rng(uint32_t seed_lo, uint32_t seed_hi, int n, uint2* out, hipStream_t stream);
 void launch_live_list(const RenderParams& p, int num_subtiles, unsigned long long* mask, unsigned* list, unsigned* count, hipStream_t stream);
 void launch_accumulate(const RenderParams& p, int owned_tiles, hipStream_t stream);

@@ -43,7 +43,22 @@
 
 #include "ptk_device.h"
 
+// This file is compiled TWICE into libptk.so.  PTK_CONTRACT 0 (default): -ffp-contract=off, the bit-exact product kernels in
+// namespace ptk.  PTK_CONTRACT >= 1: the same trace kernels in namespace ptk::fma, built with -ffp-contract=fast (the
+// compiler fuses a * b + c into v_fma_f32 wherever it appears: Moeller-Trumbore, dot products, normalisations, shading) for
+// the "contract" option of ptk_set_option: results within the north star's tolerance (RMSE <= 1e-3 per channel on the mean
+// image, asserted by tests/test_gpu_contract.py), no longer bit-identical to the oracle.  Level 2 also takes 1 / x, sqrt
+// and 1 / sqrt straight from the hardware's 1-ulp instructions.
+#ifndef PTK_CONTRACT
+#define PTK_CONTRACT 0
+#endif
+
 namespace ptk {
+#if PTK_CONTRACT >= 2
+namespace fast {
+#elif PTK_CONTRACT
+namespace fma {
+#endif
 
 #define PTK_EPS 0.00001f                        // mesh.h:12
 #define PTK_FLT_EPSILON 1.1920928955078125e-7f
@@ -88,7 +103,9 @@ __device__ __forceinline__ v3 cross(v3 x, v3 y)
 #endif
 __device__ __forceinline__ float rcp_ieee(float a)
 {
-#if PTK_SHORT_RCP
+#if PTK_CONTRACT >= 2
+    return __builtin_amdgcn_rcpf(a);
+#elif PTK_SHORT_RCP
     const float y = __builtin_amdgcn_rcpf(a);
     const float e = __builtin_fmaf(-a, y, 1.0f);
     return __builtin_fmaf(y, e, y);
@@ -99,7 +116,9 @@ __device__ __forceinline__ float rcp_ieee(float a)
 // ... plus IEEE results for zeros, infinities and NaNs (one v_div_fixup_f32): where a zero length can occur
 __device__ __forceinline__ float rcp_ieee_any(float a)
 {
-#if PTK_SHORT_RCP
+#if PTK_CONTRACT >= 2
+    return __builtin_amdgcn_rcpf(a);
+#elif PTK_SHORT_RCP
     return __builtin_amdgcn_div_fixupf(rcp_ieee(a), a, 1.0f);
 #else
     return 1.0f / a;
@@ -125,7 +144,9 @@ __device__ __forceinline__ float rcp_ieee_any(float a)
 #endif
 __device__ __forceinline__ float sqrt_ieee(float x)
 {
-#if PTK_SHORT_SQRT
+#if PTK_CONTRACT >= 2
+    return __builtin_amdgcn_sqrtf(x);
+#elif PTK_SHORT_SQRT
     if (__builtin_expect(!(x >= 0x1p-104f), 0)) return sqrtf(x);          // (zero too: correct either way, and as rare)
     float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
@@ -139,7 +160,11 @@ __device__ __forceinline__ float sqrt_ieee(float x)
 __device__ __forceinline__ v3 normalize(v3 a)
 {
     float sqr = a.x * a.x + a.y * a.y + a.z * a.z;
+#if PTK_CONTRACT >= 2
+    float inv = __builtin_amdgcn_rsqf(sqr);
+#else
     float inv = rcp_ieee_any(sqrt_ieee(sqr));
+#endif
     return muls(a, inv);
 }
 __device__ __forceinline__ v3 reflect(v3 I, v3 N)
@@ -1202,6 +1227,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
     }
 }
 
+#if !PTK_CONTRACT      // ---- everything but the trace kernels exists once, in the exact build
 // Streaming fold of the sample buffer into the float accumulator, strictly in sample order
 // (`mTotalImg[px] += color` once per RenderFrame(), pathtracer.cpp:798-800), plus the 8-bit resolve
 // (pathtracer.cpp:802-812).  One thread per pixel; each sample read is a coalesced 1 KiB per wave.
@@ -1363,6 +1389,8 @@ void launch_probe_math(int op, const float* d_in, float* d_out, int n, hipStream
     if (n > 0) hipLaunchKernelGGL(probe_math_kernel, dim3((n + PTK_BLOCK - 1) / PTK_BLOCK), dim3(PTK_BLOCK), 0, stream, op, d_in, d_out, n);
 }
 
+#endif  // !PTK_CONTRACT
+
 struct QueueGeometry { int w[QG_WORDS]; };
 __global__ void queue_init_kernel(unsigned* block, const QueueGeometry geo, const unsigned* live_count)
 {
@@ -1376,6 +1404,7 @@ __global__ void queue_init_kernel(unsigned* block, const QueueGeometry geo, cons
     if (t < QG_WORDS) ((int*)(block + 8 * PTK_QUEUE_STRIDE))[t] = w;
 }
 
+#if !PTK_CONTRACT
 // Which pixels of every owned 8x8 quadrant need tracing: on the image, and - when the camera ray's closest hit is
 // cached - not a miss (pathtracer.cpp:550: such a pixel is black for every sample).  One wave per quadrant.
 __global__ __launch_bounds__(PTK_BLOCK) void live_mask_kernel(const RenderParams P, unsigned long long* mask, int num_subtiles)
@@ -1442,9 +1471,14 @@ void launch_live_list(const RenderParams& p, int num_subtiles, unsigned long lon
     hipLaunchKernelGGL(live_compact_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)mask, num_subtiles, list, count);
 }
 
+#endif  // !PTK_CONTRACT
+
 void launch_trace(const RenderParams& p0, int num_subtiles, int resident_waves, hipStream_t stream, bool stats)
 {
     if (num_subtiles <= 0) return;
+#if PTK_CONTRACT
+    stats = false;                  // the counters belong to the exact build
+#endif
     RenderParams p = p0;
     // the items = (entry of the live list, chunk) go into 8 queues (one per XCD group) in runs of four entries; the
     // host only knows an upper bound of the list's length (every quadrant live), the device the real one
@@ -1463,12 +1497,16 @@ void launch_trace(const RenderParams& p0, int num_subtiles, int resident_waves, 
     geo.w[QG_QUOTA] = generations > 1 ? blocks : 0;
     hipLaunchKernelGGL(queue_init_kernel, dim3(1), dim3(64), 0, stream, p.queues, geo, p.live_count);
     const bool flat = p.flat_count > 0;
+#if !PTK_CONTRACT
     if (stats && flat) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
     else if (stats) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    else if (flat) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else
+#endif
+    if (flat) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
     else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
 }
 
+#if !PTK_CONTRACT
 // ---- multi-GPU exchange step: packed form of the float accumulator ---------------------------------
 // Packed layout of rank r of `world` (include/ptk.h ptk_packed_layout): its owned tiles in ascending tile order, 768
 // floats each = the tile's 16 x 16 pixels row-major from the tile's top-left, RGB; pixels off the image hold 0.
@@ -1542,4 +1580,9 @@ void launch_probe(const ProbeParams& p, hipStream_t stream)
     hipLaunchKernelGGL(probe_hits_kernel, dim3((p.n + PTK_BLOCK - 1) / PTK_BLOCK), dim3(PTK_BLOCK), 0, stream, p);
 }
 
+#endif  // !PTK_CONTRACT
+
+#if PTK_CONTRACT
+}  // namespace fma / fast
+#endif
 }  // namespace ptk
