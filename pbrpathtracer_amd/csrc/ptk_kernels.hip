@@ -575,6 +575,314 @@ __device__ __forceinline__ bool sample_direct_light(const PT& P, v3 p, v3 n, v3 
     return true;
 }
 
+// One surface interaction of PathTracer::Trace (pathtracer.cpp:551-727) for the hit W.best of the ray (W.ro, W.rd): emission,
+// Russian roulette, material branch, direction sampling, the light sample of DirectIllumimation.  Returns true when the path
+// ends here; otherwise W holds the next ray to walk (BVH kernels: the shadow ray towards the sampled light - W.occl_tri >= 0,
+// W.best = its light triangle's own hit, Tdi its contribution, nextDir the bounce direction that follows - or the bounce
+// ray itself; FLAT kernel: W the bounce ray and WS the shadow ray, tested in one pass).  Shared by every trace kernel.
+template <bool STATS, bool FLAT, class PT>
+__device__ __forceinline__ bool shade_interaction(const PT& P, Walk& W, Walk& WS, int* stack, Rng& rng, v3& L, v3& T, v3& Tdi, v3& nextDir,
+                                                  int& depth, int& iter, bool& inside, const uint32_t ray, Counters& cnt)
+{
+    const Hit h = W.best;
+    const v3 ro = W.ro, rd = W.rd;
+    if (STATS) cnt.shaded++;
+    const float4* sp4 = P.shade + (size_t)h.tri * SHADE_F4;
+    float4 s0 = ldg4(sp4);
+    int mbits = __float_as_int(s0.w);
+    int matid = mbits & 0x7fffffff;
+    bool smoothing = mbits < 0;
+    const float4* mp = P.mats + (size_t)matid * MAT_F4;
+    // the whole 96-byte material in one batch (two of its words are only needed further down: asked for there,
+    // they cost the block another memory round trip), and the vertex normals of a smoothed triangle with it
+    float4 m0 = ldg4(mp), m1 = ldg4(mp + 1), m2 = ldg4(mp + 2), m3 = ldg4(mp + 3);
+    float4 m4f = ldg4(mp + 4), m5f = ldg4(mp + 5);
+    float4 sn2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sn3 = sn2, sn4 = sn2;
+    if (smoothing) { sn2 = ldg4(sp4 + 2); sn3 = ldg4(sp4 + 3); sn4 = ldg4(sp4 + 4); }
+    asm volatile("" ::: "memory");
+    int tex_diffuse = __float_as_int(m4f.x), tex_normal = __float_as_int(m4f.y);
+    int tex_emiss = __float_as_int(m4f.z), tex_rough = __float_as_int(m4f.w);
+    int tex_metal = __float_as_int(m5f.x);
+    bool any_tex = __float_as_int(m5f.z) != 0;
+
+    v3 p = add(ro, muls(rd, h.t));                  // :553
+    float uvx = 0.0f, uvy = 0.0f;
+    if (any_tex)
+    {
+        float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
+        float w = 1.0f - h.u - h.v;                 // GetUV :533-536
+        uvx = w * s1.x + h.u * s1.z + h.v * s2.x;
+        uvy = w * s1.y + h.u * s1.w + h.v * s2.y;
+    }
+    v3 n = V(s0.x, s0.y, s0.z);
+    if (smoothing)                                  // :556, GetSmoothNormal :538-543
+    {
+        const float4 s2 = sn2, s3 = sn3, s4 = sn4;
+        float w = 1.0f - h.u - h.v;
+        v3 n1 = V(s2.z, s2.w, s3.x), n2 = V(s3.y, s3.z, s3.w), n3 = V(s4.x, s4.y, s4.z);
+        v3 sn = add(add(muls(n1, w), muls(n2, h.u)), muls(n3, h.v));
+        n = normalize(sn);
+    }
+    if (tex_normal >= 0)                            // :558-566
+    {
+        float4 s4 = ldg4(sp4 + 4), s5 = ldg4(sp4 + 5), s6 = ldg4(sp4 + 6);
+        float4 c = tex2d(P, tex_normal, uvx, uvy);
+        if (STATS) cnt.tex++;
+        v3 nt = V(c.x * 2.0f - 1.0f, c.y * 2.0f - 1.0f, c.z * 2.0f - 1.0f);
+        if (nt.z <= 0.0f) nt = V(nt.x, nt.y, PTK_EPS);
+        nt = normalize(nt);
+        v3 tg = V(s4.w, s5.x, s5.y), bt = V(s5.z, s5.w, s6.x);
+        v3 m = V(tg.x * nt.x + bt.x * nt.y + n.x * nt.z,
+                 tg.y * nt.x + bt.y * nt.y + n.y * nt.z,
+                 tg.z * nt.x + bt.z * nt.y + n.z * nt.z);
+        n = normalize(m);
+    }
+    if (dot(n, rd) > 0.0f) n = neg(n);              // :567-568
+    p = add(p, muls(n, PTK_EPS));                   // :569
+
+    bool ended = false;
+    if (!(iter < P.max_depth)) ended = true;        // :571 terminal bounce: no emission
+    else
+    {
+        v3 diffuse = V(m0.x, m0.y, m0.z);
+        if (tex_diffuse >= 0) { float4 c = tex2d(P, tex_diffuse, uvx, uvy); diffuse = V(c.x, c.y, c.z); if (STATS) cnt.tex++; }
+        v3 emiss = V(m2.x, m2.y, m2.z);
+        if (tex_emiss >= 0) { float4 c = tex2d(P, tex_emiss, uvx, uvy); emiss = V(c.x, c.y, c.z); if (STATS) cnt.tex++; }
+        float roughness = m2.w;
+        if (tex_rough >= 0) { roughness = tex2d_r(P, tex_rough, uvx, uvy); if (STATS) cnt.tex++; }
+        float reflectiveness = m3.x;
+        if (tex_metal >= 0) { reflectiveness = tex2d_r(P, tex_metal, uvx, uvy); if (STATS) cnt.tex++; }
+        const int mtype = __float_as_int(m0.w);
+        const v3 specular = V(m1.x, m1.y, m1.z);
+        const float emissI = m1.w;
+
+        depth++; iter++;                            // :586-587
+        const float prob = m3.w;                    // min(0.95, max(diffuse)) of the constant colour
+        if (depth >= P.max_depth)
+        {
+            if (fabsf(rng.next()) > prob) ended = true;     // :590-594, no 1/prob compensation
+        }
+        if (!ended)
+        {
+            v3 r = reflect(rd, n);                  // :596
+            v3 dir;
+            v3 weight;
+            bool diffuse_bounce = false;
+            // the reference spells the same three-way roughness sampler out three times
+            // (:603-624, :679-700) and the hemisphere sampler twice more (:631-636, :717-722);
+            // here the branch only picks the sampler's arguments and ONE call does the work
+            int sampler = 0;                        // 0: mirror direction r, 1: hemisphere about n, 2: lobe about r
+            if (mtype == 0)
+            {
+                if (rng.next() < reflectiveness)    // :601
+                {
+                    sampler = roughness == 1.0f ? 1 : (roughness == 0.0f ? 0 : 2);
+                    iter--;
+                    weight = specular;              // :626
+                }
+                else
+                {
+                    sampler = 1;                    // :631-636
+                    diffuse_bounce = true;
+                    weight = diffuse;               // :638
+                }
+            }
+            else
+            {
+                bool refract = false;
+                v3 refractN = n;
+                if (roughness != 0.0f)              // :645-654
+                {
+                    float w = rng.next() * roughness, th = rng.next();
+                    refractN = sample_about(n, 1.0f - PTK_FLT_EPSILON, r, n, w, th);
+                }
+                float nc = 1.0f, ng = m3.z;
+                float eta = inside ? ng / nc : nc / ng;     // :658
+                float r0 = (nc - ng) / (nc + ng);
+                r0 = r0 * r0;
+                float c = fabsf(dot(rd, refractN));
+                float k = 1.0f - eta * eta * (1.0f - c * c);
+                if (k < 0.0f) refract = false;
+                else
+                {
+                    float re = r0 + (1.0f - r0) * (1.0f - c) * (1.0f - c);    // :668
+                    if (fabsf(rng.next()) < re) refract = false;
+                    else if (rng.next() < reflectiveness) refract = false;
+                    else refract = true;
+                }
+                if (!refract)
+                {
+                    sampler = roughness == 1.0f ? 1 : (roughness == 0.0f ? 0 : 2);
+                    iter--;
+                    weight = specular;              // :702
+                }
+                else if (rng.next() < m3.y)         // :706 translucency
+                {
+                    float a = eta * dot(n, rd) + sqrt_ieee(k);
+                    dir = normalize(sub(muls(rd, eta), muls(refractN, a)));   // :708
+                    p = sub(p, muls(muls(n, PTK_EPS), 2.0f));                  // :709
+                    inside = !inside;
+                    iter--;
+                    weight = diffuse;               // :712
+                    sampler = 3;                    // direction already set
+                }
+                else
+                {
+                    sampler = 1;                    // :717-722
+                    diffuse_bounce = true;
+                    weight = diffuse;               // :724
+                }
+            }
+            if (sampler == 0) dir = r;
+            else if (sampler != 3)
+            {
+                const bool lobe = sampler == 2;
+                float w = rng.next();
+                if (lobe) w = w * roughness;
+                float th = rng.next();
+                dir = sample_about(n, lobe ? 1.0f - PTK_FLT_EPSILON : 1.0f - PTK_EPS, lobe ? r : n, lobe ? r : n, w, th);
+            }
+
+            L = add(L, mulv(T, muls(emiss, emissI)));      // emiss * emissiveIntensity term
+            v3 next_ro = p, next_rd = dir;
+            float4 lt0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), lt1 = lt0, lt2 = lt0;
+            if (diffuse_bounce && P.num_lights > 0)
+            {
+                // DirectIllumimation + SampleTriangle, pathtracer.cpp:494-531
+                const float u_light = rng.next(), u_su = rng.next(), u_sv = rng.next();
+                v3 l, di;
+                int light_tri;
+                if (sample_direct_light(P, p, n, diffuse, u_light, u_su, u_sv, l, di, light_tri, lt0, lt1, lt2))
+                {
+                    Tdi = mulv(T, di);
+                    if (FLAT)
+                    {
+                        // the shadow ray rides along with the bounce ray in the next flat pass, which finds its
+                        // closest hit over ALL triangles (no early end: the pass runs for the bounce ray anyway)
+                        WS.begin(p, l, P.num_nodes, stack);
+                        WS.occl_tri = light_tri;
+                    }
+                    else
+                    {
+                        W.occl_tri = light_tri;
+                        nextDir = dir;
+                        next_rd = l;
+                    }
+                }
+            }
+            T = mulv(T, weight);
+            W.begin(next_ro, next_rd, P.num_nodes, stack);
+            // a shadow ray meets its light triangle before anything else (see Walk::occl_tri)
+            if (!FLAT && W.occl_tri >= 0) (void)tri_test<STATS>(P, W, lt0, lt1, lt2, rng, ray, cnt);
+        }
+    }
+    return ended;
+}
+
+// ---- work distribution shared by the persistent trace kernels -------------------------------------------------------
+// the current item: read only when units are dealt, so it lives in LDS, not in registers the hot loops want
+enum { IT_NLIVE = 0, IT_X0, IT_Y0, IT_SBEGIN, IT_OUTBASE,
+       IT_STEAL,                // queues (group + steal) & 7 ... are the ones not yet seen empty; 8 = none left
+       IT_LO, IT_HI, IT_G,      // slots [lo, hi) of queue g this wave has popped and not yet used
+       IT_REMAIN,               // slots that queue had left after that pop (sizes the next batch)
+       IT_TAKEN,                // items this wave has traced so far (against the launch's per-wave quota, if any)
+       IT_NLIVE_MAGIC,          // ceil(2^32 / live pixels): unit / live pixels = mulhi(unit, magic), exact while unit * live pixels < 2^32
+       IT_WORDS };
+
+// Takes the next non-empty work item from the per-XCD queues (-> lds_item, lds_pixel_of_rank); returns its unit count, 0
+// when every queue is empty (or this wave's quota of a multi-generation launch is used up).  Wave-uniform; one wave per
+// workgroup.
+template <class PT>
+__device__ __forceinline__ uint32_t acquire_work_item(const PT& P, uint32_t* lds_item, unsigned char* lds_pixel_of_rank, const int lane)
+{
+    // the launch geometry is re-read from the queue block (one coalesced load, fields broadcast with
+    // v_readlane) instead of living in SGPRs across the hot loops, where it forced spills
+    const int geo = ((const int*)(P.queues + 8 * PTK_QUEUE_STRIDE))[lane & 15];
+    const int num_chunks = __builtin_amdgcn_readlane(geo, QG_NUM_CHUNKS), world = __builtin_amdgcn_readlane(geo, QG_WORLD);
+    const int rank = __builtin_amdgcn_readlane(geo, QG_RANK);
+    const int tiles_x = __builtin_amdgcn_readlane(geo, QG_TILES_X), chunk = __builtin_amdgcn_readlane(geo, QG_CHUNK);
+    const uint32_t spp = (uint32_t)__builtin_amdgcn_readlane(geo, QG_SPP);
+    const int slots_per_queue = __builtin_amdgcn_readlane(geo, QG_SLOTS), live_count = __builtin_amdgcn_readlane(geo, QG_LIVE_COUNT);
+    // multi-GPU runs launch several generations of waves, each retiring after its quota of items, so that the
+    // kernels of the exchange step (RCCL, on another stream) find free wave slots while this kernel is running
+    const uint32_t quota = (uint32_t)__builtin_amdgcn_readlane(geo, QG_QUOTA);
+    const int my_group = (int)blockIdx.x & 7;
+    int steal = (int)lds_item[IT_STEAL];
+    int lo = (int)lds_item[IT_LO], hi = (int)lds_item[IT_HI], cur_g = (int)lds_item[IT_G];
+    uint32_t remain = lds_item[IT_REMAIN];
+    const int pullers = max(1, (int)gridDim.x >> 3);           // waves that share one queue
+    if (quota != 0u && lds_item[IT_TAKEN] >= quota && lo >= hi) steal = 8;
+    for (;;)
+    {
+        while (lo >= hi && steal < 8)
+        {
+            // pop the next slot(s).  P.max_batch > 1 pops guided batches (a share of what is left per puller,
+            // shrinking towards the end); measured slower on every config - consecutive slots are the chunks of
+            // ONE quadrant, which are better traced by several waves at the same time - so the default is 1
+            const int g = (my_group + steal) & 7;
+            // (what the queue had left after this wave's previous pop has roughly halved since: the other
+            // pullers popped meanwhile)
+            const uint32_t left = g == cur_g && remain != 0xffffffffu ? remain / 2u : (uint32_t)slots_per_queue;
+            const int want = max(1, min(P.max_batch, (int)(left / (4u * (uint32_t)pullers))));
+            int old = 0;
+            if (lane == 0) old = (int)atomicAdd(&P.queues[g * PTK_QUEUE_STRIDE], (unsigned)want);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old < slots_per_queue)
+            {
+                lo = old; hi = min(slots_per_queue, old + want); cur_g = g;
+                remain = (uint32_t)(slots_per_queue - hi);
+                break;
+            }
+            // this queue is empty: look at all eight counters at once (one load) and move on to the next
+            // one that still has items, instead of finding each of them empty with an atomic of its own
+            unsigned seen = ~0u;
+            if (lane < 8) seen = __hip_atomic_load(&P.queues[((my_group + lane) & 7) * PTK_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned avail = (unsigned)__ballot(seen < (unsigned)slots_per_queue) & 0xffu & (0xffu << (steal + 1));
+            steal = avail ? __builtin_ctz(avail) : 8;
+            if (steal < 8)
+            {
+                // size the first pop from the victim by what it was just seen to have left
+                cur_g = (my_group + steal) & 7;
+                remain = 2u * ((uint32_t)slots_per_queue - (uint32_t)__builtin_amdgcn_readlane((int)seen, steal));
+            }
+        }
+        if (lo >= hi) break;
+        const int slot = lo++;
+        if (slot >= slots_per_queue) continue;                             // (one-item-per-wave mode: surplus block)
+        // slot -> (entry of the live list, chunk): a queue holds runs of four consecutive entries - the
+        // quadrants of one tile, as a rule - so that tile is traced within one XCD
+        const int e = slot / num_chunks, chunk_id = slot - e * num_chunks;
+        const int v = ((e >> 2) * 8 + cur_g) * 4 + (e & 3);
+        if (v >= live_count) continue;                                     // padding of the last runs
+        const int subtile = (int)P.live_list[v];                           // (owned tile) * 4 + quadrant
+        const unsigned long long live_mask = P.live_mask[subtile];         // its pixels that need tracing
+        const int item = subtile * num_chunks + chunk_id;
+        const int owned = subtile >> 2, quad = subtile & 3;
+        const int tile = owned * world + rank;
+        // rows are rotated by 3 tiles each so that a rank's tiles form diagonals, not columns (load balance)
+        const int ty = tile / tiles_x, tx = (tile % tiles_x + tiles_x - (3 * ty) % tiles_x) % tiles_x;
+        const int x0 = tx * PTK_TILE + (quad & 1) * 8, y0 = ty * PTK_TILE + (quad >> 1) * 8;
+        const uint32_t s_begin = (uint32_t)chunk_id * (uint32_t)chunk;
+        const uint32_t s_count = min((uint32_t)chunk, spp - s_begin);      // host guarantees s_begin < spp
+        const uint32_t n_live = (uint32_t)__popcll(live_mask);
+        if (n_live == 0) continue;
+        __syncthreads();                    // every lane is done with the previous item's table
+        if ((live_mask >> lane) & 1ull) lds_pixel_of_rank[__popcll(live_mask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+        if (lane == 0)
+        {
+            lds_item[IT_NLIVE] = n_live; lds_item[IT_NLIVE_MAGIC] = (uint32_t)((0x100000000ull + n_live - 1u) / n_live); lds_item[IT_X0] = (uint32_t)x0; lds_item[IT_Y0] = (uint32_t)y0;
+            lds_item[IT_SBEGIN] = s_begin; lds_item[IT_STEAL] = (uint32_t)steal; lds_item[IT_TAKEN] += 1u;
+            lds_item[IT_LO] = (uint32_t)lo; lds_item[IT_HI] = (uint32_t)hi; lds_item[IT_G] = (uint32_t)cur_g; lds_item[IT_REMAIN] = remain;
+            lds_item[IT_OUTBASE] = (uint32_t)item * (uint32_t)chunk * 64u;   // sample s of quadrant pixel q: P.samples[base + s * 64 + q]
+        }
+        __syncthreads();
+        return n_live * s_count;
+    }
+    if (lane == 0) { lds_item[IT_STEAL] = 8u; lds_item[IT_LO] = lds_item[IT_HI] = 0u; }
+    __syncthreads();
+    return 0u;
+}
+
 // (the two states that wait for a camera ray - no unit yet, unit dealt - are the two smallest: one compare counts both)
 enum : int { ST_NEED = 0, ST_GEN = 1, ST_TRAV = 2, ST_SHADE = 3, ST_DONE = 4 };
 
@@ -607,14 +915,6 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
     // of the frame per XCD was 2x slower when the dispatcher dealt the items: cheap and dear regions.)
     static_assert(PTK_TRACE_BLOCK == 64, "one wave per workgroup");
     __shared__ unsigned char lds_pixel_of_rank[64];
-    // the current item: read only when units are dealt, so it lives in LDS, not in registers the hot loops want
-    enum { IT_NLIVE = 0, IT_X0, IT_Y0, IT_SBEGIN, IT_OUTBASE,
-           IT_STEAL,                // queues (group + steal) & 7 ... are the ones not yet seen empty; 8 = none left
-           IT_LO, IT_HI, IT_G,      // slots [lo, hi) of queue g this wave has popped and not yet used
-           IT_REMAIN,               // slots that queue had left after that pop (sizes the next batch)
-           IT_TAKEN,                // items this wave has traced so far (against the launch's per-wave quota, if any)
-           IT_NLIVE_MAGIC,          // ceil(2^32 / live pixels): unit / live pixels = mulhi(unit, magic), exact while unit * live pixels < 2^32
-           IT_WORDS };
     __shared__ uint32_t lds_item[IT_WORDS];
     if (lane == 0)
     {
@@ -636,94 +936,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
     uint32_t out_idx = 0;           // its slot in the sample buffer
 
     // takes the next non-empty item (-> lds_item, lds_pixel_of_rank); returns its unit count, 0 when every queue is empty
-    auto acquire_item = [&]() -> uint32_t {
-        // the launch geometry is re-read from the queue block (one coalesced load, fields broadcast with
-        // v_readlane) instead of living in SGPRs across the hot loops, where it forced spills
-        const int geo = ((const int*)(P.queues + 8 * PTK_QUEUE_STRIDE))[lane & 15];
-        const int num_chunks = __builtin_amdgcn_readlane(geo, QG_NUM_CHUNKS), world = __builtin_amdgcn_readlane(geo, QG_WORLD);
-        const int rank = __builtin_amdgcn_readlane(geo, QG_RANK);
-        const int tiles_x = __builtin_amdgcn_readlane(geo, QG_TILES_X), chunk = __builtin_amdgcn_readlane(geo, QG_CHUNK);
-        const uint32_t spp = (uint32_t)__builtin_amdgcn_readlane(geo, QG_SPP);
-        const int slots_per_queue = __builtin_amdgcn_readlane(geo, QG_SLOTS), live_count = __builtin_amdgcn_readlane(geo, QG_LIVE_COUNT);
-        // multi-GPU runs launch several generations of waves, each retiring after its quota of items, so that the
-        // kernels of the exchange step (RCCL, on another stream) find free wave slots while this kernel is running
-        const uint32_t quota = (uint32_t)__builtin_amdgcn_readlane(geo, QG_QUOTA);
-        const int my_group = (int)blockIdx.x & 7;
-        int steal = (int)lds_item[IT_STEAL];
-        int lo = (int)lds_item[IT_LO], hi = (int)lds_item[IT_HI], cur_g = (int)lds_item[IT_G];
-        uint32_t remain = lds_item[IT_REMAIN];
-        const int pullers = max(1, (int)gridDim.x >> 3);           // waves that share one queue
-        if (quota != 0u && lds_item[IT_TAKEN] >= quota && lo >= hi) steal = 8;
-        for (;;)
-        {
-            while (lo >= hi && steal < 8)
-            {
-                // pop the next slot(s).  P.max_batch > 1 pops guided batches (a share of what is left per puller,
-                // shrinking towards the end); measured slower on every config - consecutive slots are the chunks of
-                // ONE quadrant, which are better traced by several waves at the same time - so the default is 1
-                const int g = (my_group + steal) & 7;
-                // (what the queue had left after this wave's previous pop has roughly halved since: the other
-                // pullers popped meanwhile)
-                const uint32_t left = g == cur_g && remain != 0xffffffffu ? remain / 2u : (uint32_t)slots_per_queue;
-                const int want = max(1, min(P.max_batch, (int)(left / (4u * (uint32_t)pullers))));
-                int old = 0;
-                if (lane == 0) old = (int)atomicAdd(&P.queues[g * PTK_QUEUE_STRIDE], (unsigned)want);
-                old = __builtin_amdgcn_readfirstlane(old);
-                if (old < slots_per_queue)
-                {
-                    lo = old; hi = min(slots_per_queue, old + want); cur_g = g;
-                    remain = (uint32_t)(slots_per_queue - hi);
-                    break;
-                }
-                // this queue is empty: look at all eight counters at once (one load) and move on to the next
-                // one that still has items, instead of finding each of them empty with an atomic of its own
-                unsigned seen = ~0u;
-                if (lane < 8) seen = __hip_atomic_load(&P.queues[((my_group + lane) & 7) * PTK_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned avail = (unsigned)__ballot(seen < (unsigned)slots_per_queue) & 0xffu & (0xffu << (steal + 1));
-                steal = avail ? __builtin_ctz(avail) : 8;
-                if (steal < 8)
-                {
-                    // size the first pop from the victim by what it was just seen to have left
-                    cur_g = (my_group + steal) & 7;
-                    remain = 2u * ((uint32_t)slots_per_queue - (uint32_t)__builtin_amdgcn_readlane((int)seen, steal));
-                }
-            }
-            if (lo >= hi) break;
-            const int slot = lo++;
-            if (slot >= slots_per_queue) continue;                             // (one-item-per-wave mode: surplus block)
-            // slot -> (entry of the live list, chunk): a queue holds runs of four consecutive entries - the
-            // quadrants of one tile, as a rule - so that tile is traced within one XCD
-            const int e = slot / num_chunks, chunk_id = slot - e * num_chunks;
-            const int v = ((e >> 2) * 8 + cur_g) * 4 + (e & 3);
-            if (v >= live_count) continue;                                     // padding of the last runs
-            const int subtile = (int)P.live_list[v];                           // (owned tile) * 4 + quadrant
-            const unsigned long long live_mask = P.live_mask[subtile];         // its pixels that need tracing
-            const int item = subtile * num_chunks + chunk_id;
-            const int owned = subtile >> 2, quad = subtile & 3;
-            const int tile = owned * world + rank;
-            // rows are rotated by 3 tiles each so that a rank's tiles form diagonals, not columns (load balance)
-            const int ty = tile / tiles_x, tx = (tile % tiles_x + tiles_x - (3 * ty) % tiles_x) % tiles_x;
-            const int x0 = tx * PTK_TILE + (quad & 1) * 8, y0 = ty * PTK_TILE + (quad >> 1) * 8;
-            const uint32_t s_begin = (uint32_t)chunk_id * (uint32_t)chunk;
-            const uint32_t s_count = min((uint32_t)chunk, spp - s_begin);      // host guarantees s_begin < spp
-            const uint32_t n_live = (uint32_t)__popcll(live_mask);
-            if (n_live == 0) continue;
-            __syncthreads();                    // every lane is done with the previous item's table
-            if ((live_mask >> lane) & 1ull) lds_pixel_of_rank[__popcll(live_mask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
-            if (lane == 0)
-            {
-                lds_item[IT_NLIVE] = n_live; lds_item[IT_NLIVE_MAGIC] = (uint32_t)((0x100000000ull + n_live - 1u) / n_live); lds_item[IT_X0] = (uint32_t)x0; lds_item[IT_Y0] = (uint32_t)y0;
-                lds_item[IT_SBEGIN] = s_begin; lds_item[IT_STEAL] = (uint32_t)steal; lds_item[IT_TAKEN] += 1u;
-                lds_item[IT_LO] = (uint32_t)lo; lds_item[IT_HI] = (uint32_t)hi; lds_item[IT_G] = (uint32_t)cur_g; lds_item[IT_REMAIN] = remain;
-                lds_item[IT_OUTBASE] = (uint32_t)item * (uint32_t)chunk * 64u;   // sample s of quadrant pixel q: P.samples[base + s * 64 + q]
-            }
-            __syncthreads();
-            return n_live * s_count;
-        }
-        if (lane == 0) { lds_item[IT_STEAL] = 8u; lds_item[IT_LO] = lds_item[IT_HI] = 0u; }
-        __syncthreads();
-        return 0u;
-    };
+    auto acquire_item = [&]() -> uint32_t { return acquire_work_item(P, lds_item, lds_pixel_of_rank, lane); };
 
     const v3 camPos0 = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
     const v3 camRight = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
@@ -941,200 +1154,9 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 }
 #endif
                 // ---- one surface interaction of PathTracer::Trace, pathtracer.cpp:551-727 ----
-                const Hit h = W.best;
-                const v3 ro = W.ro, rd = W.rd;
-                if (STATS) cnt.shaded++;
-                const float4* sp4 = P.shade + (size_t)h.tri * SHADE_F4;
-                float4 s0 = ldg4(sp4);
-                int mbits = __float_as_int(s0.w);
-                int matid = mbits & 0x7fffffff;
-                bool smoothing = mbits < 0;
-                const float4* mp = P.mats + (size_t)matid * MAT_F4;
-                // the whole 96-byte material in one batch (two of its words are only needed further down: asked for there,
-                // they cost the block another memory round trip), and the vertex normals of a smoothed triangle with it
-                float4 m0 = ldg4(mp), m1 = ldg4(mp + 1), m2 = ldg4(mp + 2), m3 = ldg4(mp + 3);
-                float4 m4f = ldg4(mp + 4), m5f = ldg4(mp + 5);
-                float4 sn2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sn3 = sn2, sn4 = sn2;
-                if (smoothing) { sn2 = ldg4(sp4 + 2); sn3 = ldg4(sp4 + 3); sn4 = ldg4(sp4 + 4); }
-                asm volatile("" ::: "memory");
-                int tex_diffuse = __float_as_int(m4f.x), tex_normal = __float_as_int(m4f.y);
-                int tex_emiss = __float_as_int(m4f.z), tex_rough = __float_as_int(m4f.w);
-                int tex_metal = __float_as_int(m5f.x);
-                bool any_tex = __float_as_int(m5f.z) != 0;
-
-                v3 p = add(ro, muls(rd, h.t));                  // :553
-                float uvx = 0.0f, uvy = 0.0f;
-                if (any_tex)
-                {
-                    float4 s1 = ldg4(sp4 + 1), s2 = ldg4(sp4 + 2);
-                    float w = 1.0f - h.u - h.v;                 // GetUV :533-536
-                    uvx = w * s1.x + h.u * s1.z + h.v * s2.x;
-                    uvy = w * s1.y + h.u * s1.w + h.v * s2.y;
-                }
-                v3 n = V(s0.x, s0.y, s0.z);
-                if (smoothing)                                  // :556, GetSmoothNormal :538-543
-                {
-                    const float4 s2 = sn2, s3 = sn3, s4 = sn4;
-                    float w = 1.0f - h.u - h.v;
-                    v3 n1 = V(s2.z, s2.w, s3.x), n2 = V(s3.y, s3.z, s3.w), n3 = V(s4.x, s4.y, s4.z);
-                    v3 sn = add(add(muls(n1, w), muls(n2, h.u)), muls(n3, h.v));
-                    n = normalize(sn);
-                }
-                if (tex_normal >= 0)                            // :558-566
-                {
-                    float4 s4 = ldg4(sp4 + 4), s5 = ldg4(sp4 + 5), s6 = ldg4(sp4 + 6);
-                    float4 c = tex2d(P, tex_normal, uvx, uvy);
-                    if (STATS) cnt.tex++;
-                    v3 nt = V(c.x * 2.0f - 1.0f, c.y * 2.0f - 1.0f, c.z * 2.0f - 1.0f);
-                    if (nt.z <= 0.0f) nt = V(nt.x, nt.y, PTK_EPS);
-                    nt = normalize(nt);
-                    v3 tg = V(s4.w, s5.x, s5.y), bt = V(s5.z, s5.w, s6.x);
-                    v3 m = V(tg.x * nt.x + bt.x * nt.y + n.x * nt.z,
-                             tg.y * nt.x + bt.y * nt.y + n.y * nt.z,
-                             tg.z * nt.x + bt.z * nt.y + n.z * nt.z);
-                    n = normalize(m);
-                }
-                if (dot(n, rd) > 0.0f) n = neg(n);              // :567-568
-                p = add(p, muls(n, PTK_EPS));                   // :569
-
-                bool ended = false;
-                if (!(iter < P.max_depth)) ended = true;        // :571 terminal bounce: no emission
-                else
-                {
-                    v3 diffuse = V(m0.x, m0.y, m0.z);
-                    if (tex_diffuse >= 0) { float4 c = tex2d(P, tex_diffuse, uvx, uvy); diffuse = V(c.x, c.y, c.z); if (STATS) cnt.tex++; }
-                    v3 emiss = V(m2.x, m2.y, m2.z);
-                    if (tex_emiss >= 0) { float4 c = tex2d(P, tex_emiss, uvx, uvy); emiss = V(c.x, c.y, c.z); if (STATS) cnt.tex++; }
-                    float roughness = m2.w;
-                    if (tex_rough >= 0) { roughness = tex2d_r(P, tex_rough, uvx, uvy); if (STATS) cnt.tex++; }
-                    float reflectiveness = m3.x;
-                    if (tex_metal >= 0) { reflectiveness = tex2d_r(P, tex_metal, uvx, uvy); if (STATS) cnt.tex++; }
-                    const int mtype = __float_as_int(m0.w);
-                    const v3 specular = V(m1.x, m1.y, m1.z);
-                    const float emissI = m1.w;
-
-                    depth++; iter++;                            // :586-587
-                    const float prob = m3.w;                    // min(0.95, max(diffuse)) of the constant colour
-                    if (depth >= P.max_depth)
-                    {
-                        if (fabsf(rng.next()) > prob) ended = true;     // :590-594, no 1/prob compensation
-                    }
-                    if (!ended)
-                    {
-                        v3 r = reflect(rd, n);                  // :596
-                        v3 dir;
-                        v3 weight;
-                        bool diffuse_bounce = false;
-                        // the reference spells the same three-way roughness sampler out three times
-                        // (:603-624, :679-700) and the hemisphere sampler twice more (:631-636, :717-722);
-                        // here the branch only picks the sampler's arguments and ONE call does the work
-                        int sampler = 0;                        // 0: mirror direction r, 1: hemisphere about n, 2: lobe about r
-                        if (mtype == 0)
-                        {
-                            if (rng.next() < reflectiveness)    // :601
-                            {
-                                sampler = roughness == 1.0f ? 1 : (roughness == 0.0f ? 0 : 2);
-                                iter--;
-                                weight = specular;              // :626
-                            }
-                            else
-                            {
-                                sampler = 1;                    // :631-636
-                                diffuse_bounce = true;
-                                weight = diffuse;               // :638
-                            }
-                        }
-                        else
-                        {
-                            bool refract = false;
-                            v3 refractN = n;
-                            if (roughness != 0.0f)              // :645-654
-                            {
-                                float w = rng.next() * roughness, th = rng.next();
-                                refractN = sample_about(n, 1.0f - PTK_FLT_EPSILON, r, n, w, th);
-                            }
-                            float nc = 1.0f, ng = m3.z;
-                            float eta = inside ? ng / nc : nc / ng;     // :658
-                            float r0 = (nc - ng) / (nc + ng);
-                            r0 = r0 * r0;
-                            float c = fabsf(dot(rd, refractN));
-                            float k = 1.0f - eta * eta * (1.0f - c * c);
-                            if (k < 0.0f) refract = false;
-                            else
-                            {
-                                float re = r0 + (1.0f - r0) * (1.0f - c) * (1.0f - c);    // :668
-                                if (fabsf(rng.next()) < re) refract = false;
-                                else if (rng.next() < reflectiveness) refract = false;
-                                else refract = true;
-                            }
-                            if (!refract)
-                            {
-                                sampler = roughness == 1.0f ? 1 : (roughness == 0.0f ? 0 : 2);
-                                iter--;
-                                weight = specular;              // :702
-                            }
-                            else if (rng.next() < m3.y)         // :706 translucency
-                            {
-                                float a = eta * dot(n, rd) + sqrt_ieee(k);
-                                dir = normalize(sub(muls(rd, eta), muls(refractN, a)));   // :708
-                                p = sub(p, muls(muls(n, PTK_EPS), 2.0f));                  // :709
-                                inside = !inside;
-                                iter--;
-                                weight = diffuse;               // :712
-                                sampler = 3;                    // direction already set
-                            }
-                            else
-                            {
-                                sampler = 1;                    // :717-722
-                                diffuse_bounce = true;
-                                weight = diffuse;               // :724
-                            }
-                        }
-                        if (sampler == 0) dir = r;
-                        else if (sampler != 3)
-                        {
-                            const bool lobe = sampler == 2;
-                            float w = rng.next();
-                            if (lobe) w = w * roughness;
-                            float th = rng.next();
-                            dir = sample_about(n, lobe ? 1.0f - PTK_FLT_EPSILON : 1.0f - PTK_EPS, lobe ? r : n, lobe ? r : n, w, th);
-                        }
-
-                        L = add(L, mulv(T, muls(emiss, emissI)));      // emiss * emissiveIntensity term
-                        v3 next_ro = p, next_rd = dir;
-                        float4 lt0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), lt1 = lt0, lt2 = lt0;
-                        if (diffuse_bounce && P.num_lights > 0)
-                        {
-                            // DirectIllumimation + SampleTriangle, pathtracer.cpp:494-531
-                            const float u_light = rng.next(), u_su = rng.next(), u_sv = rng.next();
-                            v3 l, di;
-                            int light_tri;
-                            if (sample_direct_light(P, p, n, diffuse, u_light, u_su, u_sv, l, di, light_tri, lt0, lt1, lt2))
-                            {
-                                Tdi = mulv(T, di);
-                                if (FLAT)
-                                {
-                                    // the shadow ray rides along with the bounce ray in the next flat pass, which finds its
-                                    // closest hit over ALL triangles (no early end: the pass runs for the bounce ray anyway)
-                                    WS.begin(p, l, P.num_nodes, stack);
-                                    WS.occl_tri = light_tri;
-                                }
-                                else
-                                {
-                                    W.occl_tri = light_tri;
-                                    nextDir = dir;
-                                    next_rd = l;
-                                }
-                            }
-                        }
-                        T = mulv(T, weight);
-                        W.begin(next_ro, next_rd, P.num_nodes, stack);
-                        // a shadow ray meets its light triangle before anything else (see Walk::occl_tri)
-                        if (!FLAT && W.occl_tri >= 0) (void)tri_test<STATS>(P, W, lt0, lt1, lt2, rng, ray, cnt);
-                        st = ST_TRAV;
-                    }
-                }
+                const bool ended = shade_interaction<STATS, FLAT>(P, W, WS, stack, rng, L, T, Tdi, nextDir, depth, iter, inside, ray, cnt);
                 if (ended) PTK_FINISH_PATH();
+                else st = ST_TRAV;
             }
         }
         else
@@ -1203,6 +1225,395 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
     }
 #undef PTK_WALK_DONE
 #undef PTK_FINISH_PATH
+    if (STATS)
+    {
+        atomicAdd(&P.stats[0], (unsigned long long)cnt.started);
+        atomicAdd(&P.stats[1], (unsigned long long)cnt.rays);
+        atomicAdd(&P.stats[2], (unsigned long long)cnt.shadow);
+        atomicAdd(&P.stats[3], (unsigned long long)cnt.nodes);
+        atomicAdd(&P.stats[4], (unsigned long long)cnt.tris);
+        atomicAdd(&P.stats[5], (unsigned long long)cnt.shaded);
+        atomicAdd(&P.stats[6], (unsigned long long)cnt.tex);
+        atomicMax(&P.stats[15], (unsigned long long)cnt.max_nodes);
+        if (lane == 0)
+        {
+            atomicAdd(&P.stats[7], (unsigned long long)cnt.walk_iters);
+            atomicAdd(&P.stats[8], (unsigned long long)cnt.walk_lanes);
+            atomicAdd(&P.stats[9], (unsigned long long)cnt.shade_execs);
+            atomicAdd(&P.stats[10], (unsigned long long)cnt.shade_lanes);
+            atomicAdd(&P.stats[11], (unsigned long long)cnt.gen_execs);
+            atomicAdd(&P.stats[12], (unsigned long long)cnt.gen_lanes);
+            atomicAdd(&P.stats[13], (unsigned long long)cnt.tri_execs);
+            atomicAdd(&P.stats[14], (unsigned long long)cnt.tri_lanes);
+        }
+    }
+}
+
+// ---- pooled BVH kernel --------------------------------------------------------------------------------------------------
+// The same megakernel - persistent one-wave workgroups, one path per lane, the same items / units / queues, walk_step and
+// shade_interaction - with MORE PATHS THAN LANES: every wave owns a pool of P.pool_slots paths (a multiple of 64) whose
+// state lives in a private block of device memory (128 B per path: a 64-byte job record the walk reads and a 64-byte
+// state record only shading touches), and alternates two phases over it:
+//   SHADE  the paths whose ray has been traced (and the units dealt into free slots) are shaded 64 at a time, compacted
+//          through a list in LDS: the shade block always runs with a full wave, instead of with the quarter to half of a
+//          wave that happen to wait for it while the other lanes walk (lane utilisation of the shade block 0.47-0.54 in
+//          trace_kernel<BVH>, profiles/r02);
+//   TRACE  the jobs (shadow ray + bounce ray of one interaction, as in trace_kernel) are dealt to the lanes dynamically:
+//          a lane whose job is finished stores the hit and takes the next job of the list, its record requested one walk
+//          iteration ahead.  The phase ends as soon as lanes run out of jobs - NOT when the last walk has finished (walk
+//          lengths are heavy-tailed: draining the wave costs more than the pool gains): the walks still in flight are
+//          SUSPENDED (ten words per lane; the lane's LDS stack column stays as it is) and resumed in the same lane when
+//          the next trace phase begins, next to the fresh jobs.  So no lane parks for shading while others walk, and none
+//          idles behind a long walk.
+// Nothing but a handful of counters is live in registers across the phases, so the walk loop is compiled without the
+// shading state and the shade block without the walk's.  Paths never leave their wave: no atomics, no barriers between
+// waves, no queue contention; the arithmetic per path is the very same sequence (same RNG stream, same order of additions
+// into L), so images are bit-identical with trace_kernel's and the oracle's.  Used for launches big enough to be
+// persistent (launch_trace decides).
+//
+// Pool record of slot s (float4 units, base = pool + s * 8):
+//   J0 = (ray origin p, bits occl_tri)           J1 = (first direction d1, bits rng.key)
+//   J2 = (second direction d2, bits ray number)  J3 = (bits tri, t, u, v)
+//      job: walk (p, d1) - a shadow ray towards light triangle occl_tri when occl_tri >= 0, J3 then holding the light
+//      triangle's own hit - then, after a shadow ray, the bounce ray (p, d2).  Result: J3 = closest hit of the bounce ray
+//      (the LAST ray), the sign bit of t set when the shadow ray found its light (t itself is positive or +inf).
+//   S0 = (L, rng.state)  S1 = (T, rng.inc)  S2 = (Tdi, bits depth)  S3 = (bits pix, bits out_idx, bits iter | inside << 31,
+//      bits fresh: 0x80000000 | sample index when the slot holds a unit that has not been started yet)
+// Suspend record of lane l (behind the slots: pool + pool_slots * 8 + l * 2):
+//   X0 = (bits node, bits flags, bits tri_next, bits slot)   X1 = best (bits tri, t, u, v)
+//      flags: bits 0-7 stack entries, 8-11 tri_left, 16 lit, 17 the bounce ray of the job is being walked, 31 in use
+#ifndef PTK_POOL_MAX
+#define PTK_POOL_MAX 256            // (slot numbers travel through LDS as bytes; with the 8 KiB stack 16 waves still fit a CU's LDS)
+#endif
+#define PTK_POOL_F4(slots) ((slots) * 8 + 128)      // float4 per workgroup: the slots + 64 suspend records
+enum : int { J_NEED = 0, J_LOAD = 1, J_WALK = 2 };
+
+template <bool STATS>
+__global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES_BVH) void trace_pool_kernel(const RenderParams P)
+{
+    __shared__ int lds_stack[PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
+    __shared__ unsigned char lds_jobs[PTK_POOL_MAX], lds_done[PTK_POOL_MAX], lds_free[PTK_POOL_MAX];
+    static_assert(PTK_POOL_MAX <= 256, "slot numbers are bytes");
+    __shared__ unsigned char lds_pixel_of_rank[64];
+    __shared__ uint32_t lds_item[IT_WORDS];
+    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.exit_gen) return;     // Exit() named this render
+    static_assert(PTK_TRACE_BLOCK == 64, "one wave per workgroup");
+    const int lane = threadIdx.x;
+    int* const stack = lds_stack + lane;
+    const int pool_slots = P.pool_slots;
+    float4* const pool = P.pool + (size_t)blockIdx.x * (size_t)PTK_POOL_F4(pool_slots);
+    float4* const susp = pool + pool_slots * 8 + lane * 2;
+    if (lane == 0)
+    {
+        lds_item[IT_STEAL] = 0u; lds_item[IT_LO] = 0u; lds_item[IT_HI] = 0u;
+        lds_item[IT_G] = (uint32_t)blockIdx.x & 7u;
+        lds_item[IT_REMAIN] = 0xffffffffu;
+        lds_item[IT_TAKEN] = 0u;
+    }
+    for (int i = lane; i < pool_slots; i += 64) lds_free[i] = (unsigned char)i;
+    __syncthreads();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t total_units = 0, next_unit = 0;    // wave-uniform: the item being dealt
+    bool units_left = true;
+    int n_jobs = 0, n_done = 0, n_free = pool_slots;    // wave-uniform list lengths
+    unsigned long long m_susp = 0ull;           // lanes whose walk is suspended (its state is in `susp`)
+
+    const v3 camPos0 = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    const v3 camRight = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
+    const v3 camUp = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
+    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+
+    for (;;)
+    {
+        // ---- REFILL: units are dealt into the free slots; such a slot only holds (pixel, sample, output slot) until the
+        // shade phase below starts its path
+        while (n_free > 0 && units_left)
+        {
+            if (next_unit >= total_units)
+            {
+                next_unit = 0;
+                // (readfirstlane: the value comes out of LDS, which the compiler takes for lane-dependent - and with it every
+                // count derived from it, turning the phase loops' wave-uniform exits into exec-masked ones)
+                total_units = (uint32_t)__builtin_amdgcn_readfirstlane((int)acquire_work_item(P, lds_item, lds_pixel_of_rank, lane));
+                if (total_units == 0) { units_left = false; break; }
+            }
+            const int take = min(min(64, n_free), (int)(total_units - next_unit));
+            if (lane < take)
+            {
+                const uint32_t n_live = lds_item[IT_NLIVE];
+                const uint32_t u = next_unit + (uint32_t)lane;
+                const uint32_t s_in_chunk = n_live == 1u ? u : __umulhi(u, lds_item[IT_NLIVE_MAGIC]);
+                const uint32_t q = lds_pixel_of_rank[u - s_in_chunk * n_live];
+                const uint32_t pix = (lds_item[IT_Y0] + (q >> 3)) * (uint32_t)P.width + lds_item[IT_X0] + (q & 7u);
+                const uint32_t sample_abs = lds_item[IT_SBEGIN] + s_in_chunk;
+                const uint32_t out_idx = lds_item[IT_OUTBASE] + s_in_chunk * 64u + q;
+                const int slot = lds_free[n_free - 1 - lane];
+                pool[slot * 8 + 7] = make_float4(__uint_as_float(pix), __uint_as_float(out_idx), 0.0f, __uint_as_float(0x80000000u | sample_abs));
+                lds_done[n_done + lane] = (unsigned char)slot;
+            }
+            n_free -= take; n_done += take; next_unit += (uint32_t)take;
+        }
+        if (n_done == 0 && n_jobs == 0 && m_susp == 0ull) break;          // no unit left to deal and no path alive
+        __syncthreads();
+
+        // ---- SHADE phase: everything on the done list -----------------------------------------------------------------
+        for (int c = 0; c < n_done; c += 64)
+        {
+            const int k = c + lane;
+            const bool act = k < n_done;
+            const int slot = act ? (int)lds_done[k] : 0;
+            float4* const rec = pool + slot * 8;
+            bool has_job = false, finished = false;
+            if (STATS) { const uint32_t na = (uint32_t)__popcll(__ballot(act)); if (lane == 0) { cnt.shade_execs++; cnt.shade_lanes += na; } }
+            if (act)
+            {
+                const float4 S3 = rec[7];
+                const uint32_t pix = __float_as_uint(S3.x), out_idx = __float_as_uint(S3.y), fresh = __float_as_uint(S3.w);
+                Walk W, WS;
+                Rng rng;
+                v3 L, T, Tdi = V(0.0f, 0.0f, 0.0f), nextDir = V(0.0f, 0.0f, 1.0f);
+                int depth, iter;
+                bool inside, need_shade = false;
+                uint32_t ray;
+                W.occl_tri = -1; W.node = NODE_EXIT; W.top = stack; W.tri_next = 0; W.tri_left = 0;
+                if (fresh != 0u)
+                {
+                    // a unit dealt since the last shade phase: its path starts here
+                    const uint2 pr = P.pixel_rng[pix];
+                    rng.inc = pr.y;
+                    rng.state = hash32(P.first_sample + (fresh & 0x7fffffffu) + pr.x);
+                    rng.key = rng.state;
+                    L = V(0.0f, 0.0f, 0.0f); T = V(1.0f, 1.0f, 1.0f);
+                    depth = 0; iter = 0; inside = false;
+                    if (STATS) cnt.started++;
+                    if (P.primary_hit)
+                    {
+                        // pinhole camera, no stochastic opacity: the camera ray's hit is cached per pixel (see trace_kernel);
+                        // the two SampleCircle draws only advance the stream
+                        rng.state = rng.state * (747796405u * 747796405u) + rng.inc * (747796405u + 1u);
+                        const float4 ch = P.primary_hit[pix], r = P.primary_rd[pix];
+                        W.ro = camPos0; W.rd = V(r.x, r.y, r.z);
+                        W.best.tri = __float_as_int(ch.x); W.best.t = ch.y; W.best.u = ch.z; W.best.v = ch.w;
+                        ray = 1;
+                        need_shade = true;      // (pixels whose camera ray misses are never dealt)
+                    }
+                    else
+                    {
+                        // ---- camera ray with thin-lens DOF, pathtracer.cpp:785-791 + SampleCircle :734-739 ----
+                        const float4 d0 = P.primary[pix];
+                        const v3 dir0 = V(d0.x, d0.y, d0.z);
+                        v3 focalPoint = add(camPos0, muls(dir0, P.focal_dist));
+                        float r1 = rng.next(), r2 = rng.next();          // always two draws, even with a pinhole
+                        v3 ro = camPos0;
+                        if (P.aperture != 0.0f)
+                        {
+                            float angle = (float)((double)r1 * 2. * PTK_PI_D);
+                            float radius = sqrt_ieee(r2);
+                            float sn, cs;
+                            sincos_2pi(angle, sn, cs);
+                            float offx = (cs * radius) * P.aperture, offy = (sn * radius) * P.aperture;
+                            ro = add(camPos0, add(muls(camRight, offx), muls(camUp, offy)));
+                        }
+                        v3 rd = normalize(sub(focalPoint, ro));
+                        W.ro = ro; W.rd = rd;
+                        W.best.tri = PTK_NOHIT; W.best.t = __builtin_inff(); W.best.u = 0.0f; W.best.v = 0.0f;
+                        ray = 0;
+                        has_job = true;
+                    }
+                }
+                else
+                {
+                    const float4 J0 = rec[0], J1 = rec[1], J2 = rec[2], J3 = rec[3], S0 = rec[4], S1 = rec[5], S2 = rec[6];
+                    L = V(S0.x, S0.y, S0.z); T = V(S1.x, S1.y, S1.z); Tdi = V(S2.x, S2.y, S2.z);
+                    rng.state = __float_as_uint(S0.w); rng.inc = __float_as_uint(S1.w); rng.key = __float_as_uint(J1.w);
+                    depth = __float_as_int(S2.w);
+                    iter = (int)(__float_as_uint(S3.z) & 0x7fffffffu); inside = (__float_as_uint(S3.z) >> 31) != 0u;
+                    const bool had_shadow = __float_as_int(J0.w) >= 0;
+                    // pathtracer.cpp:522-526: the shadow ray found its light - DirectIllumimation's value joins L before
+                    // anything the bounce ray leads to (the order trace_kernel adds in)
+                    if (had_shadow && __float_as_int(J3.y) < 0) L = add(L, Tdi);
+                    ray = __float_as_uint(J2.w) + (had_shadow ? 2u : 1u);
+                    const int tri = __float_as_int(J3.x);
+                    if (tri == PTK_NOHIT) finished = true;              // :550 miss -> black
+                    else
+                    {
+                        W.ro = V(J0.x, J0.y, J0.z);
+                        W.rd = had_shadow ? V(J2.x, J2.y, J2.z) : V(J1.x, J1.y, J1.z);
+                        W.best.tri = tri; W.best.t = fabsf(J3.y); W.best.u = J3.z; W.best.v = J3.w;
+                        need_shade = true;
+                    }
+                }
+                if (need_shade)
+                {
+                    const bool ended = shade_interaction<STATS, false>(P, W, WS, stack, rng, L, T, Tdi, nextDir, depth, iter, inside, ray, cnt);
+                    finished = ended; has_job = !ended;
+                }
+                if (finished) P.samples[out_idx] = make_float4(L.x, L.y, L.z, 0.0f);
+                if (has_job)
+                {
+                    rec[0] = make_float4(W.ro.x, W.ro.y, W.ro.z, __int_as_float(W.occl_tri));
+                    rec[1] = make_float4(W.rd.x, W.rd.y, W.rd.z, __uint_as_float(rng.key));
+                    rec[2] = make_float4(nextDir.x, nextDir.y, nextDir.z, __uint_as_float(ray));
+                    rec[3] = make_float4(__int_as_float(W.best.tri), W.best.t, W.best.u, W.best.v);
+                    rec[4] = make_float4(L.x, L.y, L.z, __uint_as_float(rng.state));
+                    rec[5] = make_float4(T.x, T.y, T.z, __uint_as_float(rng.inc));
+                    rec[6] = make_float4(Tdi.x, Tdi.y, Tdi.z, __int_as_float(depth));
+                    rec[7] = make_float4(S3.x, S3.y, __uint_as_float((uint32_t)iter | (inside ? 0x80000000u : 0u)), 0.0f);
+                }
+            }
+            // a path either has a job for the next trace phase or returns its slot (the job list is empty when shading
+            // begins: the trace phase only ends once every job has been dealt)
+            const unsigned long long m_job = __ballot(has_job), m_fin = __ballot(finished);
+            if (has_job) lds_jobs[n_jobs + __popcll(m_job & lt_mask)] = (unsigned char)slot;
+            if (finished) lds_free[n_free + __popcll(m_fin & lt_mask)] = (unsigned char)slot;
+            n_jobs += __popcll(m_job); n_free += __popcll(m_fin);
+        }
+        n_done = 0;
+        __syncthreads();                        // the job records are read by other lanes than wrote them
+        if (n_jobs == 0 && m_susp == 0ull) continue;
+
+        // ---- TRACE phase: the suspended walks resume, the list's jobs are dealt to whichever lane is free -------------------
+        {
+            Walk W;
+            W.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0, stack);
+            W.occl_tri = -1;
+            Rng rng; rng.inc = 1u; rng.state = 0u; rng.key = 0u;      // (the walk only needs the key: stochastic opacity)
+            v3 nextDir = V(0.0f, 0.0f, 1.0f);
+            float4 tj0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), tj1 = tj0, tj2 = tj0, tj3 = tj0;   // the job record in flight
+            uint32_t ray = 0;
+            int jst = J_NEED, slot_cur = 0;
+            bool lit = false;
+            if ((m_susp >> lane) & 1ull)
+            {
+                const float4 X0 = susp[0], X1 = susp[1];
+                const uint32_t fl = __float_as_uint(X0.y);
+                slot_cur = __float_as_int(X0.w);
+                const float4* rec = pool + slot_cur * 8;
+                const float4 J0 = rec[0], J1 = rec[1], J2 = rec[2];
+                const bool in_bounce = (fl >> 17) & 1u, had_shadow = __float_as_int(J0.w) >= 0;
+                // (the second ray of a job with a shadow ray goes along d2; any other ray along d1)
+                W.begin(V(J0.x, J0.y, J0.z), (in_bounce && had_shadow) ? V(J2.x, J2.y, J2.z) : V(J1.x, J1.y, J1.z), P.num_nodes, stack);
+                W.occl_tri = in_bounce ? -1 : __float_as_int(J0.w);
+                rng.key = __float_as_uint(J1.w);
+                nextDir = V(J2.x, J2.y, J2.z);
+                ray = __float_as_uint(J2.w) + ((in_bounce && had_shadow) ? 1u : 0u);
+                W.node = __float_as_int(X0.x);
+                W.top = stack + (int)(fl & 255u) * PTK_TRACE_BLOCK;
+                W.tri_left = (int)((fl >> 8) & 15u);
+                W.tri_next = __float_as_int(X0.z);
+                W.best.tri = __float_as_int(X1.x); W.best.t = X1.y; W.best.u = X1.z; W.best.v = X1.w;
+                lit = (fl >> 16) & 1u;
+                jst = J_WALK;
+            }
+            int next = 0, dg = 0;               // wave-uniform: next job to deal; lane-iterations spent waiting for a job
+            bool stop = false;                  // wave-uniform; ONE loop exit and no `continue`: the loop's latch stays a scalar branch
+            do
+            {
+                // a job whose record was requested in the previous iteration starts walking: its loads were in flight
+                // behind that iteration's node and triangle records
+                bool fin = false;               // this lane finished a job in this iteration
+                if (jst == J_LOAD)
+                {
+                    W.begin(V(tj0.x, tj0.y, tj0.z), V(tj1.x, tj1.y, tj1.z), P.num_nodes, stack);
+                    W.occl_tri = __float_as_int(tj0.w);
+                    rng.key = __float_as_uint(tj1.w);
+                    nextDir = V(tj2.x, tj2.y, tj2.z);
+                    ray = __float_as_uint(tj2.w);
+                    if (W.occl_tri >= 0) { W.best.tri = __float_as_int(tj3.x); W.best.t = tj3.y; W.best.u = tj3.z; W.best.v = tj3.w; }
+                    lit = false;
+                    jst = J_WALK;
+                    if (W.done())                          // (a scene without a single node: every ray misses)
+                    {
+                        pool[slot_cur * 8 + 3] = make_float4(__int_as_float(PTK_NOHIT), __builtin_inff(), 0.0f, 0.0f);
+                        jst = J_NEED; fin = true;
+                    }
+                }
+                const unsigned long long m_tq = __ballot(W.tri_left > 0), m_nr = __ballot(W.node >= 0);
+                const int n_walk = __popcll(m_tq | m_nr);
+                const unsigned long long m_need = __ballot(jst == J_NEED);
+                const int n_need = __popcll(m_need);
+                // (wave-uniform by construction; said explicitly so that the loop's branches stay scalar)
+                next = __builtin_amdgcn_readfirstlane(next); dg = __builtin_amdgcn_readfirstlane(dg);
+                n_done = __builtin_amdgcn_readfirstlane(n_done);
+                if (n_need > 0)
+                {
+                    if (next < n_jobs)
+                    {
+                        if (n_walk == 0 || dg * 8 >= P.fetch_thr * n_walk)
+                        {
+                            const int k = next + __popcll(m_need & lt_mask);
+                            if (STATS) { const uint32_t nf = (uint32_t)min(n_need, n_jobs - next); if (lane == 0) { cnt.gen_execs++; cnt.gen_lanes += nf; } }
+                            if (jst == J_NEED && k < n_jobs)
+                            {
+                                slot_cur = (int)lds_jobs[k];
+                                const float4* rec = pool + slot_cur * 8;
+                                tj0 = rec[0]; tj1 = rec[1]; tj2 = rec[2]; tj3 = rec[3];
+                                jst = J_LOAD;
+                            }
+                            next = min(n_jobs, next + n_need);
+                            dg = 0;
+                        }
+                    }
+                    else if ((n_walk == 0 || dg * 8 >= P.switch_thr * 64) && __ballot(jst == J_LOAD) == 0ull)
+                    {
+                        // every job has been dealt and lanes are waiting: the phase ends here if there is anything to shade
+                        // or to deal, with the walks in flight suspended - and in any case when nobody walks
+                        stop = n_walk == 0 || n_done + __popcll(__ballot(fin)) > 0 || (units_left && n_free > 0);
+                    }
+                }
+                if (!stop && n_walk > 0)
+                {
+                    dg += n_need;
+                    if (STATS && lane == 0) { cnt.walk_iters++; cnt.walk_lanes += (uint32_t)n_walk; }
+                    // the triangle arm is voted as in trace_kernel
+                    const int n_tq = __popcll(m_tq), n_nr = __popcll(m_nr);
+                    const bool run_tri_arm = (n_tq > 0) & ((n_nr == 0) | (n_tq * 8 >= P.tri_thr * n_nr));
+                    if (STATS && lane == 0 && run_tri_arm) { cnt.tri_execs++; cnt.tri_lanes += (uint32_t)n_tq; }
+                    if (jst == J_WALK)
+                    {
+                        walk_step<STATS, PTK_TRACE_BLOCK>(P, W, rng, ray, stack, cnt, run_tri_arm);
+                        if (W.done())
+                        {
+                            if (STATS) { cnt.rays++; cnt.max_nodes = max(cnt.max_nodes, cnt.cur_nodes); cnt.cur_nodes = 0; }
+                            ray++;
+                            const bool hit_ = W.best.tri != PTK_NOHIT;
+                            if (W.occl_tri >= 0)
+                            {
+                                // pathtracer.cpp:522-526: lit unless something else is closest; the bounce ray follows at once
+                                if (STATS) cnt.shadow++;
+                                lit = !(hit_ && W.best.tri != W.occl_tri);
+                                W.occl_tri = -1;
+                                W.begin(W.ro, nextDir, P.num_nodes, stack);
+                            }
+                            else
+                            {
+                                pool[slot_cur * 8 + 3] = make_float4(__int_as_float(W.best.tri), lit ? -W.best.t : W.best.t, W.best.u, W.best.v);
+                                jst = J_NEED; fin = true;
+                            }
+                        }
+                    }
+                }
+                // finished jobs go onto the done list for the next shade phase
+                const unsigned long long m_fin = __ballot(fin);
+                if (fin) lds_done[n_done + __popcll(m_fin & lt_mask)] = (unsigned char)slot_cur;
+                n_done += __popcll(m_fin);
+            } while (!stop);
+            // suspend the walks in flight: ten words per lane; the LDS stack column stays as it is (nothing in the shade
+            // phase touches the stack), and the walk resumes in this very lane
+            const bool walking = jst == J_WALK;
+            m_susp = __ballot(walking);
+            if (walking)
+            {
+                const bool in_bounce = W.occl_tri < 0;
+                const uint32_t fl = (uint32_t)((W.top - stack) / PTK_TRACE_BLOCK) | ((uint32_t)W.tri_left << 8) | (lit ? 1u << 16 : 0u) |
+                                    (in_bounce ? 1u << 17 : 0u) | 0x80000000u;
+                susp[0] = make_float4(__int_as_float(W.node), __uint_as_float(fl), __int_as_float(W.tri_next), __int_as_float(slot_cur));
+                susp[1] = make_float4(__int_as_float(W.best.tri), W.best.t, W.best.u, W.best.v);
+            }
+            n_jobs = 0;
+        }
+        __syncthreads();                        // the results are read by other lanes than wrote them
+    }
     if (STATS)
     {
         atomicAdd(&P.stats[0], (unsigned long long)cnt.started);
@@ -1497,12 +1908,16 @@ void launch_trace(const RenderParams& p0, int num_subtiles, int resident_waves, 
     geo.w[QG_QUOTA] = generations > 1 ? blocks : 0;
     hipLaunchKernelGGL(queue_init_kernel, dim3(1), dim3(64), 0, stream, p.queues, geo, p.live_count);
     const bool flat = p.flat_count > 0;
+    // the pooled kernel (more paths than lanes) needs persistent waves: one private pool block per workgroup
+    const bool pooled = !flat && p.persistent && p.pool != nullptr && p.pool_slots >= 64 && blocks <= p.pool_blocks;
 #if !PTK_CONTRACT
     if (stats && flat) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else if (stats && pooled) hipLaunchKernelGGL((trace_pool_kernel<true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
     else if (stats) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
     else
 #endif
     if (flat) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    else if (pooled) hipLaunchKernelGGL((trace_pool_kernel<false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
     else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
 }
 

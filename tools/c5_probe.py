@@ -16,7 +16,7 @@ for kv in os.environ.get("PTK_OPTS", "").split(","):
         k, v = kv.split("="); ctx.set_option(k, float(v))
 print("bvh", ctx.bvh_info(), ctx.bvh_layout())
 ctx.set_option("overlap", 0)
-for rep in range(3):
+for rep in range(int(os.environ.get("PTK_PROBE_REPS", "3"))):
     ctx.reset(); t0 = time.time(); ctx.render(0, spp, 1); ctx.synchronize(); t1 = time.time()
     tm, am = ctx.last_kernel_ms()
     W, H = pt.GetResolution()
