@@ -92,7 +92,7 @@ struct ptk_ctx {
     // trace_pool_kernel's path pools, one per trace stream (index 2: the non-overlapped path): blocks x slots x 128 B
     float4* d_pool[3] = { nullptr, nullptr, nullptr };
     size_t pool_bytes[3] = { 0, 0, 0 };
-    int opt_pool = 256;                          // paths per wave of the pooled BVH kernel (multiple of 64, <= 256); 0: trace_kernel<BVH>
+    int opt_pool = 0;                            // paths per wave of the pooled BVH kernel (multiple of 64, <= 256); 0: trace_kernel<BVH>
     int opt_switch_thr = 16;                     // eighths of a wave-iteration: how long lanes may wait, all jobs dealt, before the trace phase ends
     int opt_fetch_thr = 3;                       // eighths: a free lane takes its next job once its waiting outweighs fetch_thr/8 x walking lanes
     hipStream_t trace_stream[2] = { nullptr, nullptr };

@@ -17,7 +17,7 @@ def ctx():
     from pbrpathtracer_amd import ptk
     c = ptk.Context(0)
     yield c
-    for k, v in (("persistent", -1), ("pool", 256), ("fetch_threshold", 3), ("switch_threshold", 16), ("flat", 1), ("chunk", 0)):
+    for k, v in (("persistent", -1), ("pool", 0), ("fetch_threshold", 3), ("switch_threshold", 16), ("flat", 1), ("chunk", 0)):
         c.set_option(k, v)
     c.close()
 
