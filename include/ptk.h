@@ -146,9 +146,10 @@ int ptk_read_accum(ptk_ctx* ctx, float* host_out);
 int ptk_write_accum(ptk_ctx* ctx, const float* host_in, int samples);   /* resume from a saved accumulator */
 
 int ptk_samples(ptk_ctx* ctx);         /* GetSamples (pathtracer.cpp:362-365); thread-safe */
-/* Exit (pathtracer.cpp:819-822); thread-safe.  Cuts the render in flight: passes whose kernels have not started are
+/* Exit (pathtracer.cpp:819-822); thread-safe.  Cuts EVERY render in flight - ptk_render is asynchronous while no output
+ * image is bound, so several may be queued: all of them, not only the newest - : passes whose kernels have not started are
  * skipped whole (an aborted pass adds nothing to the accumulator), the sample count still advances as mSamples does;
- * the next ptk_render clears the request, as RenderFrame() resets mExit on entry (pathtracer.cpp:742) */
+ * renders issued after the call are not affected, as RenderFrame() resets mExit on entry (pathtracer.cpp:742) */
 int ptk_request_exit(ptk_ctx* ctx);
 int ptk_synchronize(ptk_ctx* ctx);
 const char* ptk_last_error(ptk_ctx* ctx);
@@ -208,7 +209,16 @@ int ptk_probe_unpack(ptk_ctx* ctx, int world, const float* host_packed /* all ra
  * triangle arm of the BVH walk runs once the lanes holding a leaf reach this many eighths of the lanes
  * that can still walk (default 4; 0 = every iteration); "device_build" = 0/1 (default 1): build the BVH of scenes of >= 4096 triangles on the GPU;
  * "primary_cache" = 0/1, reuse the camera ray's closest
- * hit across samples when the camera is a pinhole and the scene has no opacity texture (default 1). */
+ * hit across samples when the camera is a pinhole and the scene has no opacity texture (default 1);
+ * "pool" = paths per wave of the pooled BVH kernel (trace_pool_kernel: 64..256, a multiple of 64; default 0 = the one-path-per-lane
+ * megakernel), "fetch_threshold" / "switch_threshold" = its scheduling lambdas in eighths (defaults 3 / 16);
+ * "bvh_leaf_max" (1..8), "bvh_trav_cost" (SAH cost of a node visit in triangle tests), "bvh_verbose" = builder tuning, process-wide,
+ * effective at the next ptk_upload_scene (0 = the builders' own choices: 4 / 1.0 / quiet): they shape the tree, and closest hits do
+ * not depend on the tree.
+ * ONE option changes results, within the stated tolerance: "contract" = 0 (default: every kernel bit-identical to the CPU oracle),
+ * 1 = the trace kernels built with -ffp-contract=fast (a * b + c fuses), 2 = ... and 1-ulp hardware reciprocal / square root / rsq:
+ * per-channel RMSE of the mean image against the exact kernels <= 1e-3 (measured ~1e-5 .. 9e-5, tests/test_gpu_contract.py).
+ * No environment variable reaches the library. */
 int ptk_set_option(ptk_ctx* ctx, const char* name, double value);
 
 /* measurement: HIP-event times of the last ptk_render's kernels (per pass, summed).  With the "overlap" option on and

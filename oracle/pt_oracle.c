@@ -324,7 +324,9 @@ static inline void test_triangle(const orc_scene* s, int tri, v3 ro, v3 rd, rng_
     const float* p = s->verts + (size_t)tri * 9;
     float t, u, v;
     if (!intersect_triangle(ro, rd, ld3(p), ld3(p + 3), ld3(p + 6), &t, &u, &v)) return;
-    if (!(t < best->t || (t == best->t && tri < best->tri))) return;
+    /* (an infinite t - an overflowed determinant of a ray far outside every scene - is no hit: with best->t starting at
+       infinity the tie rule would otherwise accept it; the kernels test the same) */
+    if (!(t < INFINITY) || !(t < best->t || (t == best->t && tri < best->tri))) return;
     int otex = s->mats[s->material[tri]].tex[5];
     if (otex >= 0)
     {

@@ -10,12 +10,14 @@
 #include <limits>
 
 namespace ptk {
+
+BvhTuning g_bvh_tuning;
 namespace {
 
 constexpr int32_t NODE_EXIT_CODE = INT32_MIN;     // = NODE_EXIT of ptk_device.h: a link the walk never follows
 
 constexpr int kBins = 16;
-float kTravCost = 1.0f;             // one node record = two slab tests (PTK_TRAV_COST overrides, experiments)
+float kTravCost = 1.0f;             // one node record = two slab tests (ptk_set_option "bvh_trav_cost" overrides, experiments)
 constexpr float kTriCost = 1.0f;
 
 struct Box {
@@ -307,8 +309,8 @@ bool build_bvh(const float* verts, int32_t n, int max_depth, int leaf_max, Built
     // a dependent 64-byte fetch.  Measured on MI355X (tools/perf_probe.py): two 6-triangle leaves under
     // one node beat the 5-node tree by 16 % on the 12-triangle box; larger scenes prefer <= 4 per leaf.
     if (n <= 16) { leaf_max = 8; kTravCost = 2.0f; }
-    if (const char* e = std::getenv("PTK_LEAF_MAX")) leaf_max = std::atoi(e);          // experiments only
-    if (const char* e = std::getenv("PTK_TRAV_COST")) kTravCost = (float)std::atof(e);
+    if (g_bvh_tuning.leaf_max > 0) leaf_max = g_bvh_tuning.leaf_max;                   // ptk_set_option "bvh_leaf_max" / "bvh_trav_cost"
+    if (g_bvh_tuning.trav_cost > 0.0f) kTravCost = g_bvh_tuning.trav_cost;
     if (leaf_max < 1) leaf_max = 1;
     if (leaf_max > 8) leaf_max = 8;
     if ((int64_t)n >= (1ll << 27)) return false;     // leaf code packs first << 3 into 31 bits

@@ -26,4 +26,9 @@ struct BuiltBvh {
 // leaf_max: 1..8 triangles per leaf.  Returns false if the stack bound cannot be met.
 bool build_bvh(const float* verts, int32_t n, int max_depth, int leaf_max, BuiltBvh& out);
 
+// Builder tuning of both builders (ptk_set_option "bvh_leaf_max", "bvh_trav_cost", "bvh_verbose"): 0 = the builders' own
+// choices.  They shape the tree, never a result (closest hits do not depend on the tree).
+struct BvhTuning { int leaf_max = 0; float trav_cost = 0.0f; int verbose = 0; };
+extern BvhTuning g_bvh_tuning;
+
 }  // namespace ptk

@@ -13,6 +13,7 @@
 // Child centroid bounds are not tracked per bin: a child inherits the parent's centroid bounds cut at the split plane and
 // clipped to its own box (a superset), so trees differ slightly from the host's; closest hits do not depend on the tree.
 #include "bvh_device.h"
+#include "bvh_build.h"
 
 #include <algorithm>
 #include <chrono>
@@ -536,9 +537,9 @@ bool build_bvh_device(const float* d_verts, int32_t n, int max_stack, int leaf_m
     if (n < 2 || (int64_t)n >= (1ll << 27)) { if (err) *err = "triangle count outside the device builder's range"; return false; }
     leaf_max = std::min(std::max(leaf_max, 1), 8);
     float trav_cost = 1.0f;             // SAH: one node visit in units of one triangle test
-    if (const char* e = std::getenv("PTK_TRAV_COST")) if (*e) trav_cost = (float)std::atof(e);      // experiments only
+    if (g_bvh_tuning.trav_cost > 0.0f) trav_cost = g_bvh_tuning.trav_cost;                          // ptk_set_option "bvh_trav_cost"
     const auto t0 = std::chrono::steady_clock::now();
-    const bool verbose = std::getenv("PTK_BVH_TIMING") != nullptr;      // developer diagnostics: phase times on stderr
+    const bool verbose = g_bvh_tuning.verbose != 0;                     // ptk_set_option "bvh_verbose": phase times on stderr
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
 
     const size_t node_cap = (size_t)2 * n + 2;

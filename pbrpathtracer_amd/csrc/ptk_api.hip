@@ -65,8 +65,8 @@ struct ptk_ctx {
     int rank = 0, world = 1;
 
     std::atomic<int> samples{ 0 };
-    std::atomic<uint32_t> exit_req{ 0 };
-    std::atomic<uint32_t> render_gen{ 1 };       // generation of the render in flight: Exit() names it, later renders are not affected
+    std::atomic<uint32_t> render_gen{ 1 };       // generation of the newest render: Exit() names it and thereby every render still in flight (kernels stand down
+                                                 // when the named generation >= their own); renders issued afterwards are not affected
     uint32_t* d_exit = nullptr;
     unsigned long long* d_stats = nullptr;
     unsigned* d_queues = nullptr;                // item queues of trace_kernel's persistent waves
@@ -120,6 +120,7 @@ struct ptk_ctx {
     hipEvent_t ev_rendered = nullptr, ev_packed = nullptr, ev_gathered = nullptr;
     float* d_packed = nullptr; size_t packed_floats = 0;      // non-root: this rank's packed tiles; root: every rank's, back to back
     float* d_gathered = nullptr; size_t gathered_floats = 0;  // root: the combined image (W*H*3, rows bottom-up)
+    int gathered_w = 0, gathered_h = 0;          // the frame the last ptk_gather_accum combined (ptk_read_gathered refuses any other)
     bool gather_pending = false;
 
     static constexpr int kMaxTimedPasses = 64;
@@ -461,7 +462,7 @@ int ptk_create(ptk_ctx** out, int device_ordinal)
     }
     if (hipMalloc(&c->d_exit, sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_exit, 0, sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&c->d_stats, 16 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc(&c->d_queues, (8 * PTK_QUEUE_STRIDE + QG_WORDS) * sizeof(unsigned)) != hipSuccess)
+        hipMalloc(&c->d_queues, PTK_QUEUE_BLOCK_BYTES) != hipSuccess)
     {
         ptk_destroy(c);
         return PTK_ERR_HIP;
@@ -473,7 +474,7 @@ int ptk_create(ptk_ctx** out, int device_ordinal)
         if (hipStreamCreateWithFlags(&c->trace_stream[b], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_trace_done[b], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_acc_done[b], hipEventDisableTiming) != hipSuccess ||
-            hipMalloc(&c->d_queues2[b], (8 * PTK_QUEUE_STRIDE + QG_WORDS) * sizeof(unsigned)) != hipSuccess)
+            hipMalloc(&c->d_queues2[b], PTK_QUEUE_BLOCK_BYTES) != hipSuccess)
         { ptk_destroy(c); return PTK_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming) != hipSuccess) { ptk_destroy(c); return PTK_ERR_HIP; }
     {
@@ -589,7 +590,7 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
         HIPCHK(c, hipMemcpyAsync(d_verts, s->verts, (size_t)n * 9 * sizeof(float), hipMemcpyHostToDevice, c->stream));
         std::string derr;
         int leaf_max = 4;
-        if (const char* e = std::getenv("PTK_LEAF_MAX")) if (*e) leaf_max = std::atoi(e);            // experiments only
+        if (g_bvh_tuning.leaf_max > 0) leaf_max = g_bvh_tuning.leaf_max;                              // ptk_set_option "bvh_leaf_max"
         on_device = build_bvh_device(d_verts, n, PTK_MAX_BVH_DEPTH, leaf_max, c->stream, dbvh, &derr);
         if (on_device && dbvh.stack_need > PTK_MAX_BVH_DEPTH) { (void)hipFree(dbvh.d_nodes); (void)hipFree(dbvh.d_order); on_device = false; }
     }
@@ -787,6 +788,10 @@ int ptk_set_camera(ptk_ctx* c, const float pos[3], const float dir[3], const flo
                    float focal, float fovy_deg, float focal_dist, float aperture)
 {
     if (!c || !pos || !dir || !up) return PTK_ERR_BAD_ARG;
+    // the same bound as for scene coordinates (ptk_upload_scene): the kernels' short reciprocal and the implied u > 1 test
+    // of the triangle intersection hold while ray origins stay below 2^61
+    for (int a = 0; a < 3; a++)
+        if (!(std::fabs(pos[a]) < 2.305843e18f)) return fail(c, PTK_ERR_LIMIT, "camera position is not finite or exceeds 2^61");
     for (int a = 0; a < 3; a++) c->cam_pos[a] = pos[a];
     normalize3(dir, c->cam_dir);                           // pathtracer.cpp:336
     normalize3(up, c->cam_up);                             // pathtracer.cpp:337
@@ -845,7 +850,6 @@ int ptk_reset(ptk_ctx* c)
     HIPCHK(c, hipMemsetAsync(accum_ptr(c), 0, px * 3 * sizeof(float), c->stream));     // pathtracer.cpp:745-751
     HIPCHK(c, hipMemsetAsync(c->d_rgb8, 0, px * 3, c->stream));
     c->samples = 0;
-    c->exit_req = 0;                             // (an earlier Exit() named an earlier render's generation: nothing to clear on the device)
     return PTK_OK;
 }
 
@@ -863,7 +867,6 @@ int ptk_render(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uint64_t s
     // call renders again.
     // (an Exit() names the generation of the render it interrupts; this render gets a new one, so nothing needs clearing
     // and consecutive renders stay free to overlap)
-    c->exit_req = 0;
     c->render_gen.fetch_add(1);
     int rc = ensure_primary(c);
     if (rc != PTK_OK) return rc;
@@ -950,7 +953,6 @@ int ptk_samples(ptk_ctx* c) { return c ? c->samples.load() : 0; }
 int ptk_request_exit(ptk_ctx* c)
 {
     if (!c) return PTK_ERR_BAD_ARG;
-    c->exit_req = 1;
     // blocks that have not started yet read the flag and return (kernel prologue); written with a
     // blocking copy outside the render stream so it lands while a render is in flight
     uint32_t gen = c->render_gen.load();
@@ -1124,6 +1126,7 @@ int ptk_gather_accum(ptk_ctx* c, void* rccl_comm, int root)
     {
         launch_unpack_all(c->d_packed, bases, c->d_gathered, W, H, world, c->xstream);
         HIPCHK(c, hipGetLastError());
+        c->gathered_w = W; c->gathered_h = H;
     }
     HIPCHK(c, hipEventRecord(c->ev_gathered, c->xstream));
     c->gather_pending = true;
@@ -1143,15 +1146,22 @@ int ptk_gather_wait(ptk_ctx* c)
 int ptk_gathered_device_ptr(ptk_ctx* c, void** dev_ptr, size_t* bytes)
 {
     if (!c || !dev_ptr) return PTK_ERR_BAD_ARG;
+    *dev_ptr = nullptr;
+    if (bytes) *bytes = 0;
+    if (!c->d_gathered || c->gathered_w == 0) return fail(c, PTK_ERR_BAD_ARG, "no gathered image on this rank (not the root, or ptk_gather_accum not called)");
+    if (c->gathered_w != c->width || c->gathered_h != c->height)
+        return fail(c, PTK_ERR_BAD_ARG, "the gathered image was combined for another resolution: call ptk_gather_accum again after ptk_set_frame");
     *dev_ptr = c->d_gathered;
-    if (bytes) *bytes = c->gathered_floats * sizeof(float);
-    return *dev_ptr ? PTK_OK : fail(c, PTK_ERR_BAD_ARG, "no gathered image on this rank (not the root, or ptk_gather_accum not called)");
+    if (bytes) *bytes = (size_t)c->gathered_w * c->gathered_h * 3 * sizeof(float);
+    return PTK_OK;
 }
 
 int ptk_read_gathered(ptk_ctx* c, float* host_out)
 {
     if (!c || !host_out) return PTK_ERR_BAD_ARG;
-    if (!c->d_gathered) return fail(c, PTK_ERR_BAD_ARG, "no gathered image on this rank (not the root, or ptk_gather_accum not called)");
+    if (!c->d_gathered || c->gathered_w == 0) return fail(c, PTK_ERR_BAD_ARG, "no gathered image on this rank (not the root, or ptk_gather_accum not called)");
+    if (c->gathered_w != c->width || c->gathered_h != c->height)
+        return fail(c, PTK_ERR_BAD_ARG, "the gathered image was combined for another resolution: call ptk_gather_accum again after ptk_set_frame");
     int rc = ptk_gather_wait(c);
     if (rc != PTK_OK) return rc;
     HIPCHK(c, hipMemcpy(host_out, c->d_gathered, (size_t)c->width * c->height * 3 * sizeof(float), hipMemcpyDeviceToHost));
@@ -1245,6 +1255,13 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     if (!std::strcmp(name, "overlap"))
     {
         c->opt_overlap = value != 0.0 ? 1 : 0;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "bvh_leaf_max") || !std::strcmp(name, "bvh_trav_cost") || !std::strcmp(name, "bvh_verbose"))
+    {
+        // builder tuning (process-wide, takes effect at the next ptk_upload_scene; 0 = the builders' own choices)
+        if (!(value >= 0 && value <= 64)) return fail(c, PTK_ERR_BAD_ARG, "builder tuning value must be in [0, 64]");
+        if (name[4] == 'l') g_bvh_tuning.leaf_max = (int)value; else if (name[4] == 't') g_bvh_tuning.trav_cost = (float)value; else g_bvh_tuning.verbose = (int)value;
         return PTK_OK;
     }
     if (!std::strcmp(name, "pool"))

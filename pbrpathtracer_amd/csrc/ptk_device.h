@@ -83,8 +83,8 @@ struct RenderParams {
     const float4* primary_rd;   // [H][W] its unit direction (valid with primary_hit)
     float* accum;               // [H][W][3] float RGB, rows bottom-up (mTotalImg)
     uint8_t* rgb8;              // [H][W][3] RGB8, rows bottom-up (mOutImg)
-    const uint32_t* exit_flag;  // holds the generation of the render an Exit() was aimed at (0: none)
-    uint32_t exit_gen;          // this render's generation: its kernels stand down when *exit_flag == exit_gen
+    const uint32_t* exit_flag;  // holds the generation of the newest render an Exit() was aimed at (0: none)
+    uint32_t exit_gen;          // this render's generation: its kernels stand down when *exit_flag >= exit_gen (Exit() cuts everything in flight)
     unsigned long long* stats;  // 7 counters (STATS variant only)
     int num_nodes, num_lights;
     int flat_shade_w, flat_gen_w; // FLAT block-choice weights (eighths) of the shade / camera-ray blocks vs the triangle pass
@@ -123,6 +123,12 @@ struct ProbeParams {
     int num_lights;
 };
 
+// Queue block of one trace launch: 8 slot counters (one per 128-B line) + QG_WORDS of launch geometry + the launch's
+// RenderParams.  The trace kernels take the parameters BY POINTER into this block (constant address space: every field is
+// an s_load where it is used) instead of by value: a by-value RenderParams is preloaded whole into SGPRs, which cost the
+// product kernels 30 / 42 spilled SGPRs (v_writelane / v_readlane at the head of the shade block) and three to five VGPRs.
+constexpr size_t PTK_QUEUE_BLOCK_BYTES = ((8 * PTK_QUEUE_STRIDE + QG_WORDS) * sizeof(unsigned) + 63) / 64 * 64 + (sizeof(RenderParams) + 63) / 64 * 64;
+inline const RenderParams* queue_block_params(const unsigned* block) { return (const RenderParams*)((const char*)block + ((8 * PTK_QUEUE_STRIDE + QG_WORDS) * sizeof(unsigned) + 63) / 64 * 64); }
 void launch_trace(const RenderParams& p, int num_subtiles, int resident_waves, hipStream_t stream, bool stats);
 // the same trace kernels from the second and third builds of ptk_kernels.hip (-ffp-contract=fast; `fast` also with the
 // hardware's 1-ulp reciprocal / square root): the "contract" option, results within tolerance instead of bit-exact

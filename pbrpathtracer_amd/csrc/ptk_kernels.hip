@@ -219,7 +219,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float unorm8(uint32_t b) { return (float)((double)b * (1.0 / 255.0)); }
 
 // ---- Image::tex2D (image.cpp:63-86), nearest + repeat, RGBA8 atlas -----------------------------------
-__device__ __forceinline__ float4 tex2d(const RenderParams& P, int tex, float uvx, float uvy)
+template <class PT>
+__device__ __forceinline__ float4 tex2d(const PT& P, int tex, float uvx, float uvy)
 {
     int4 ti = P.texinfo[tex];
     float u = uvx - truncf(uvx);              // == fmodf(uvx, 1.0f), exact
@@ -332,7 +333,10 @@ __device__ __forceinline__ bool tri_test(const PT& P, Walk& W, float4 t0, float4
     // (the reference also returns on u > 1, pathtracer.cpp:393: implied here - v >= 0 makes fl(u + v) >= u, rounding being
     // monotone, so u > 1 fails the u + v test, and a NaN u passes both forms alike)
     bool ok = !(fabsf(a) < PTK_EPS) & !(u < 0.0f) & !(v < 0.0f) & !(u + v > 1.0f) & (t > PTK_EPS);
-    ok = ok & ((t < W.best.t) | ((t == W.best.t) & (tri < W.best.tri)));
+    // (t < inf: with a ray origin ~1e30 away q overflows, v is NaN, t +inf - the reference rejects that on u > 1 or on a NaN
+    // of its own; without the test the tie rule below would take t == best.t == inf for a hit.  ptk_set_camera bounds the
+    // camera position, so only a path that has already left every float range could get here)
+    ok = ok & (t < __builtin_inff()) & ((t < W.best.t) | ((t == W.best.t) & (tri < W.best.tri)));
     int otex = __float_as_int(t2.z);
     if (ok && otex >= 0)
     {
@@ -891,10 +895,14 @@ enum : int { ST_NEED = 0, ST_GEN = 1, ST_TRAV = 2, ST_SHADE = 3, ST_DONE = 4 };
 // wave, operands broadcast from SGPRs, no vector memory traffic and no LDS stack), and the whole walk
 // is one block of the state machine, so lanes re-synchronise by themselves.
 template <bool STATS, bool FLAT>
-__global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRACE_WAVES_BVH)) void trace_kernel(const RenderParams P)
+__global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRACE_WAVES_BVH)) void trace_kernel(const RenderParams* __restrict__ Pp)
 {
+    // the parameters live in the launch's queue block, in the constant address space: fields are s_load-ed where they are
+    // used instead of being preloaded whole into SGPRs (ptk_device.h: 30 / 42 SGPR spills -> 0)
+    typedef const __attribute__((address_space(4))) RenderParams ConstParams;
+    ConstParams& P = *(ConstParams*)(uintptr_t)Pp;
     __shared__ int lds_stack[FLAT ? 1 : PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
-    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.exit_gen) return;     // Exit() named this render
+    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.exit_gen) return;     // an Exit() named this render or a later one
 
     const int tid = threadIdx.x;
     int* stack = lds_stack + tid;
@@ -1289,14 +1297,16 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
 enum : int { J_NEED = 0, J_LOAD = 1, J_WALK = 2 };
 
 template <bool STATS>
-__global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES_BVH) void trace_pool_kernel(const RenderParams P)
+__global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES_BVH) void trace_pool_kernel(const RenderParams* __restrict__ Pp)
 {
+    typedef const __attribute__((address_space(4))) RenderParams ConstParams;      // (see trace_kernel)
+    ConstParams& P = *(ConstParams*)(uintptr_t)Pp;
     __shared__ int lds_stack[PTK_MAX_BVH_DEPTH * PTK_TRACE_BLOCK];
     __shared__ unsigned char lds_jobs[PTK_POOL_MAX], lds_done[PTK_POOL_MAX], lds_free[PTK_POOL_MAX];
     static_assert(PTK_POOL_MAX <= 256, "slot numbers are bytes");
     __shared__ unsigned char lds_pixel_of_rank[64];
     __shared__ uint32_t lds_item[IT_WORDS];
-    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.exit_gen) return;     // Exit() named this render
+    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.exit_gen) return;     // an Exit() named this render or a later one
     static_assert(PTK_TRACE_BLOCK == 64, "one wave per workgroup");
     const int lane = threadIdx.x;
     int* const stack = lds_stack + lane;
@@ -1646,7 +1656,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void accumulate_kernel(const RenderParam
 {
     // an aborted pass adds nothing: trace waves that saw the exit flag returned without writing their samples, so the
     // sample buffer may hold another pass's values (the reference adds nothing for the rows it skips, pathtracer.cpp:779-780)
-    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.exit_gen) return;     // Exit() named this render
+    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.exit_gen) return;     // an Exit() named this render or a later one
     const int tid = threadIdx.x;
     const int lane = tid & 63, quad = tid >> 6;
     const int owned = blockIdx.x;
@@ -1803,9 +1813,20 @@ void launch_probe_math(int op, const float* d_in, float* d_out, int n, hipStream
 #endif  // !PTK_CONTRACT
 
 struct QueueGeometry { int w[QG_WORDS]; };
-__global__ void queue_init_kernel(unsigned* block, const QueueGeometry geo, const unsigned* live_count)
+static_assert(sizeof(RenderParams) % 4 == 0, "copied word by word");
+__device__ __forceinline__ RenderParams* queue_block_params_dev(unsigned* block)
+{
+    return (RenderParams*)((char*)block + ((8 * PTK_QUEUE_STRIDE + QG_WORDS) * sizeof(unsigned) + 63) / 64 * 64);
+}
+__global__ void queue_init_kernel(unsigned* block, const QueueGeometry geo, const unsigned* live_count, const RenderParams params)
 {
     const int t = threadIdx.x;
+    // the launch's parameter block, which the trace kernel reads through the constant address space
+    {
+        const uint32_t* src = (const uint32_t*)&params;
+        uint32_t* dst = (uint32_t*)queue_block_params_dev(block);
+        for (int i = t; i < (int)(sizeof(RenderParams) / 4); i += 64) dst[i] = src[i];
+    }
     if (t < 8) block[t * PTK_QUEUE_STRIDE] = 0u;
     int w = t < QG_WORDS ? geo.w[t] : 0;
     const int n = (int)*live_count;
@@ -1906,19 +1927,20 @@ void launch_trace(const RenderParams& p0, int num_subtiles, int resident_waves, 
     const int generations = p.persistent ? std::max(1, std::min(p.generations, padded / resident_waves)) : 1;
     const int blocks = p.persistent ? resident_waves * generations : padded;
     geo.w[QG_QUOTA] = generations > 1 ? blocks : 0;
-    hipLaunchKernelGGL(queue_init_kernel, dim3(1), dim3(64), 0, stream, p.queues, geo, p.live_count);
+    hipLaunchKernelGGL(queue_init_kernel, dim3(1), dim3(64), 0, stream, p.queues, geo, p.live_count, p);
+    const RenderParams* dp = queue_block_params(p.queues);
     const bool flat = p.flat_count > 0;
     // the pooled kernel (more paths than lanes) needs persistent waves: one private pool block per workgroup
     const bool pooled = !flat && p.persistent && p.pool != nullptr && p.pool_slots >= 64 && blocks <= p.pool_blocks;
 #if !PTK_CONTRACT
-    if (stats && flat) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    else if (stats && pooled) hipLaunchKernelGGL((trace_pool_kernel<true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    else if (stats) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    if (stats && flat) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, dp);
+    else if (stats && pooled) hipLaunchKernelGGL((trace_pool_kernel<true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, dp);
+    else if (stats) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, dp);
     else
 #endif
-    if (flat) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    else if (pooled) hipLaunchKernelGGL((trace_pool_kernel<false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
-    else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, p);
+    if (flat) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, dp);
+    else if (pooled) hipLaunchKernelGGL((trace_pool_kernel<false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, dp);
+    else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, dp);
 }
 
 #if !PTK_CONTRACT

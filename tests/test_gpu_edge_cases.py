@@ -126,7 +126,21 @@ def test_bad_arguments_are_errors(ctx):
         ctx.set_tile(2, 2)
     with pytest.raises(ptk.PtkError):
         ctx.set_option("no_such_option", 1)
+    # coordinates the kernels' exact short reciprocal does not cover are refused at both doors: vertices ...
+    bad = dict(a); bad["verts"] = a["verts"].copy(); bad["verts"][0, 0] = np.float32(3e18)
+    with pytest.raises(ptk.PtkError, match="2\\^61"):
+        ctx.upload_scene(bad)
+    bad["verts"][0, 0] = np.float32(np.nan)
+    with pytest.raises(ptk.PtkError):
+        ctx.upload_scene(bad)
+    # ... and the camera position (ray origins): DESIGN.md, documented difference 7
+    cam = _cam(z)
+    for v in (np.float32(3e18), np.float32(np.inf), np.float32(np.nan)):
+        far = dict(cam); far["pos"] = np.array([0.0, v, 0.0], np.float32)
+        with pytest.raises(ptk.PtkError, match="camera position"):
+            ctx.set_camera(**far)
     ctx.upload_scene(a)                                        # the context stays usable
+    ctx.set_camera(**cam)
 
 
 def test_flat_and_bvh_walks_agree(ctx, oracle_mod):

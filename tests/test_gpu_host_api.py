@@ -177,6 +177,41 @@ def test_exit_from_another_thread(tmp_path):
     pt.close(); ref.close(); ref2.close()
 
 
+def test_exit_cuts_every_render_in_flight(tmp_path):
+    """ptk_render is asynchronous while no output image is bound, so several renders can be queued when Exit() arrives: it
+    cuts ALL of them (kernels stand down when the named generation >= their own), not only the newest - an older render still
+    executing would otherwise run to its end behind the UI's back.  Two renders of 1024 samples in 8-sample passes are queued
+    and Exit() follows at once: what was accumulated is a whole number of passes (bit for bit a prefix) and FEWER than the
+    first render's alone."""
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer
+    pts, scene, _ = S.build_config("C4", str(tmp_path), width=640, height=360, grid=60)
+    pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(5)
+    pt.RenderFrames(1)
+    ctx = pt.context()
+    ctx.set_option("pass_bytes", float(32 << 20))            # 8 samples per pass
+    ctx.reset()
+    ctx.render(0, 1024, 5); ctx.render(1024, 1024, 5)          # both only queued: nothing waits for them
+    ctx.request_exit()
+    ctx.synchronize()
+    aborted = ctx.read_accum()
+    assert np.isfinite(aborted).all()
+    ref = PathTracer(0); ref.LoadSceneFile(pts); ref.SetSeed(5); ref.RenderFrames(1)
+    rctx = ref.context(); rctx.set_option("pass_bytes", float(32 << 20)); rctx.reset()
+    done, match = 0, not aborted.any()
+    while not match and done < 1024:
+        rctx.render(done, 8, 5); done += 8
+        match = np.array_equal(rctx.read_accum(), aborted)
+    assert match, "not a whole number of passes of the first render: an older render ran on after Exit()"
+    assert done < 1024
+    print(f"Exit() right after queueing 2 x 1024 samples: {done} samples were accumulated")
+    # renders issued after the Exit() are not affected
+    ctx.reset(); ctx.render(0, 8, 5)
+    rctx.reset(); rctx.render(0, 8, 5)
+    assert np.array_equal(ctx.read_accum(), rctx.read_accum())
+    pt.close(); ref.close()
+
+
 def test_material_edits_after_build_take_effect(tmp_path, oracle_mod):
     """SetMaterial after BuildBVH: the reference's triangles point into the loaded materials, so the next RenderFrame()
     uses the edited values without a rebuild (pathtracer.cpp:243-258) while the light list stays BuildBVH's.  Here the
