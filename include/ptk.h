@@ -136,6 +136,15 @@ int ptk_render(ptk_ctx* ctx, uint32_t first_sample, uint32_t spp_count, uint64_t
 /* the host-buffer hand-off of mOutImg (pathtracer.cpp:802-812, main.cpp:3026-3029):
  * W*H*3 bytes, RGB, rows bottom-up, tightly packed; waits for the stream */
 int ptk_resolve_rgb8(ptk_ctx* ctx, uint8_t* host_out);
+/* SetOutImage (pathtracer.cpp:297-300) for the interactive loop - one RenderFrame(), one glTexSubImage2D(texData)
+ * (main.cpp:3587, :3026-3029): binds the caller's W*H*3 hand-off buffer so that the accumulate kernel's 8-bit resolve
+ * (pathtracer.cpp:802-812) is written STRAIGHT into it over PCIe, and ptk_resolve_rgb8 into the bound buffer only waits
+ * for the stream - no copy command, no second launch.  A buffer from ptk_host_alloc is used as it is; any other buffer
+ * (`new GLubyte[w*h*3]`, main.cpp:3435) is page-locked in place for as long as it is bound.  If neither works the call
+ * still succeeds and ptk_resolve_rgb8 copies as before.  NULL unbinds; ptk_set_frame with another resolution unbinds too
+ * (the caller reallocates texData then, main.cpp:3425-3446).  The buffer stays caller-owned; while bound, renders run on
+ * the context's stream alone (each frame is waited for anyway). */
+int ptk_bind_out_image(ptk_ctx* ctx, uint8_t* host_out);
 /* Page-locked host memory for the hand-off buffer (what `new GLubyte[w*h*3]` is in main.cpp:3435): a
  * ptk_resolve_rgb8 into it is one DMA transfer instead of a staged copy.  Caller-owned, like texData:
  * release with ptk_host_free before the context that allocated it is destroyed or after - either order. */
@@ -180,6 +189,9 @@ int ptk_packed_layout(int width, int height, int rank, int world, int64_t* src_i
 int ptk_comm_unique_id(void* id_out /* 128 bytes */);
 int ptk_comm_init(ptk_ctx* ctx, const void* id /* 128 bytes */, int rank, int world);
 int ptk_comm_destroy(ptk_ctx* ctx);
+/* what the context's communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) and the HIP
+ * ordinal of the context: lets a benchmark line prove how many RCCL ranks the exchange really spans */
+int ptk_comm_info(ptk_ctx* ctx, int* rank, int* world, int* comm_device, int* ctx_device);
 
 /* Start the exchange of the accumulator as it is after everything queued on the context's stream so far.
  * rccl_comm: an ncclComm_t passed as void*, or NULL for the context's own (ptk_comm_init).  Asynchronous, on the

@@ -62,6 +62,12 @@ struct ptk_ctx {
     float* d_accum = nullptr;        // owned accumulator
     float* d_accum_bound = nullptr;  // caller-owned accumulator (ptk_bind_accum) or null
     uint8_t* d_rgb8 = nullptr;
+    // hand-off buffer bound by ptk_bind_out_image: the caller's pointer, its device-visible alias, whether this context
+    // page-locked it, and whether the next accumulate kernel must write every pixel (after binding, reset, a camera or
+    // scene change: the set of always-black pixels may have changed)
+    uint8_t* out_host = nullptr; uint8_t* out_host_dev = nullptr;
+    bool out_registered = false;
+    std::atomic<bool> out_full_next{ true };
     int rank = 0, world = 1;
 
     std::atomic<int> samples{ 0 };
@@ -255,6 +261,7 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     p.max_batch = c->opt_max_batch;
     p.persistent = c->opt_persistent;
     p.generations = c->opt_generations > 0 ? c->opt_generations : (c->world > 1 ? 2 : 1);
+    p.rgb8_host = nullptr; p.rgb8_host_full = 1;
     p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.exit_gen = c->render_gen.load(); p.stats = c->d_stats;
     p.num_nodes = c->num_nodes; p.num_lights = c->num_lights;
     p.flat_count = (c->opt_flat && c->num_tris <= 16 && c->d_flat_tris) ? c->num_tris : 0;
@@ -268,6 +275,12 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     for (int a = 0; a < 3; a++) { p.cam_pos[a] = c->cam_pos[a]; p.cam_right[a] = c->cam_right[a]; p.cam_up[a] = c->cam_up[a]; }
     p.focal_dist = c->focal_dist; p.aperture = c->aperture;
     p.resolve_samples = (float)(first + spp);
+}
+
+void unbind_out_image(ptk_ctx* c)
+{
+    if (c->out_registered && c->out_host) { (void)hipHostUnregister(c->out_host); (void)hipGetLastError(); }
+    c->out_host = nullptr; c->out_host_dev = nullptr; c->out_registered = false; c->out_full_next = true;
 }
 
 int owned_tiles(const RenderParams& p)
@@ -294,6 +307,7 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
             HIPCHK(c, hipGetLastError());
             c->primary_hit_dirty = false;
             c->hit_generation++;
+            c->out_full_next = true;
             c->inputs_dirty = true;
         }
         p.primary_hit = c->d_primary_hit; p.primary_rd = c->d_primary_rd;
@@ -306,6 +320,11 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         c->inputs_dirty = true;
     }
     p.pixel_rng = c->d_pixel_rng;
+    if (rgb8 == c->d_rgb8 && c->out_host_dev)
+    {
+        // (after the primary-hit cache has been brought up to date: a recomputed cache changes which pixels are always black)
+        p.rgb8_host = c->out_host_dev; p.rgb8_host_full = c->out_full_next.exchange(false) ? 1 : 0;
+    }
     const int tiles = owned_tiles(p);
     c->last_passes = 0; c->last_launches = 0;
     if (tiles == 0) return PTK_OK;
@@ -350,7 +369,9 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         const int chunk = (int)std::min<uint32_t>(n, (uint32_t)chunk_opt);
         const int num_chunks = (int)((n + chunk - 1) / chunk);
         const size_t need = per_sample * (size_t)chunk * num_chunks;
-        const bool overlap = c->opt_overlap != 0 && c->trace_stream[0] != nullptr;
+        // (a bound hand-off buffer means the caller waits for every frame: nothing to overlap, and one stream is two event
+        // hops per frame less)
+        const bool overlap = c->opt_overlap != 0 && c->trace_stream[0] != nullptr && !(c->out_host_dev && rgb8 == c->d_rgb8);
         const int b = (int)(c->pass_counter & 1u);
         hipStream_t tstream = overlap ? c->trace_stream[b] : c->stream;
         if (overlap)
@@ -495,6 +516,7 @@ void ptk_destroy(ptk_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    unbind_out_image(c);
     dfree(c->d_nodes); dfree(c->d_tris); dfree(c->d_shade); dfree(c->d_mats); dfree(c->d_lights);
     dfree(c->d_flat_tris);
     dfree(c->d_texinfo); dfree(c->d_texels); dfree(c->d_primary); dfree(c->d_primary_hit); dfree(c->d_primary_rd); dfree(c->d_accum); dfree(c->d_rgb8);
@@ -826,6 +848,7 @@ int ptk_set_frame(ptk_ctx* c, int width, int height, int max_depth)
         HIPCHK(c, hipMalloc(&c->d_rgb8, px * 3));
         c->width = width; c->height = height;
         c->d_accum_bound = nullptr;
+        unbind_out_image(c);                     // another resolution: the caller's buffer has another size (main.cpp:3425-3446)
         HIPCHK(c, hipMemsetAsync(c->d_accum, 0, px * 3 * sizeof(float), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_rgb8, 0, px * 3, c->stream));
         c->samples = 0;
@@ -850,6 +873,12 @@ int ptk_reset(ptk_ctx* c)
     HIPCHK(c, hipMemsetAsync(accum_ptr(c), 0, px * 3 * sizeof(float), c->stream));     // pathtracer.cpp:745-751
     HIPCHK(c, hipMemsetAsync(c->d_rgb8, 0, px * 3, c->stream));
     c->samples = 0;
+    if (c->out_host_dev)
+    {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memset(c->out_host, 0, px * 3);
+    }
+    c->out_full_next = true;
     return PTK_OK;
 }
 
@@ -909,11 +938,56 @@ int ptk_collect_stats(ptk_ctx* c, uint32_t first_sample, uint32_t spp_count, uin
     return PTK_OK;
 }
 
+int ptk_bind_out_image(ptk_ctx* c, uint8_t* host_out)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (host_out == c->out_host) return PTK_OK;
+    if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));      // nothing may still be writing into the old buffer
+    unbind_out_image(c);
+    if (!host_out) return PTK_OK;
+    if (c->width <= 0 || !c->d_rgb8) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    c->out_host = host_out;
+    std::memset(host_out, 0, (size_t)c->width * c->height * 3);     // pixels that are black for every sample are written once at most
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, host_out, 0) == hipSuccess && dev) c->out_host_dev = (uint8_t*)dev;       // ptk_host_alloc / already page-locked
+    else
+    {
+        (void)hipGetLastError();
+        const size_t bytes = (size_t)c->width * c->height * 3;
+        if (hipHostRegister(host_out, bytes, hipHostRegisterMapped) == hipSuccess)
+        {
+            if (hipHostGetDevicePointer(&dev, host_out, 0) == hipSuccess && dev) { c->out_host_dev = (uint8_t*)dev; c->out_registered = true; }
+            else (void)hipHostUnregister(host_out);
+        }
+        (void)hipGetLastError();                 // not lockable: ptk_resolve_rgb8 keeps copying, which is always correct
+    }
+    c->out_full_next = true;
+    return PTK_OK;
+}
+
 int ptk_resolve_rgb8(ptk_ctx* c, uint8_t* host_out)
 {
     if (!c || !host_out) return PTK_ERR_BAD_ARG;
     if (!c->d_rgb8) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
     HIPCHK(c, hipSetDevice(c->device));
+    if (host_out == c->out_host && c->out_host_dev && !c->out_full_next)
+    {
+        // bound: the accumulate kernel of the last render has written the frame there (out_full_next is only set while no
+        // render has filled the buffer since it was bound / reset).  The interactive loop waits for a frame of a few hundred
+        // microseconds: poll the stream for a while before handing the wait to the runtime, whose blocking wait costs
+        // tens of microseconds to wake up
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;)
+        {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) return PTK_OK;
+            if (q != hipErrorNotReady) return fail(c, PTK_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return PTK_OK;
+    }
     HIPCHK(c, hipMemcpyAsync(host_out, c->d_rgb8, (size_t)c->width * c->height * 3, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PTK_OK;
@@ -945,6 +1019,7 @@ int ptk_write_accum(ptk_ctx* c, const float* host_in, int samples)
     HIPCHK(c, hipMemcpyAsync(accum_ptr(c), host_in, (size_t)c->width * c->height * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->samples = samples;
+    c->out_full_next = true;
     return PTK_OK;
 }
 
@@ -956,6 +1031,7 @@ int ptk_request_exit(ptk_ctx* c)
     // blocks that have not started yet read the flag and return (kernel prologue); written with a
     // blocking copy outside the render stream so it lands while a render is in flight
     uint32_t gen = c->render_gen.load();
+    c->out_full_next = true;                     // a cut render may have skipped a full write of the bound hand-off buffer
     (void)hipSetDevice(c->device);
     (void)hipMemcpy(c->d_exit, &gen, sizeof(gen), hipMemcpyHostToDevice);
     return PTK_OK;
@@ -1047,6 +1123,20 @@ int ptk_comm_init(ptk_ctx* c, const void* id_in, int rank, int world)
     if (r != ncclSuccess) { c->comm = nullptr; return fail(c, PTK_ERR_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
     c->comm_rank = rank; c->comm_world = world;
     c->rank = rank; c->world = world;            // the frame is split over the group (ptk_set_tile)
+    return PTK_OK;
+}
+
+int ptk_comm_info(ptk_ctx* c, int* rank, int* world, int* comm_device, int* ctx_device)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    if (ctx_device) *ctx_device = c->device;
+    if (!c->comm) return fail(c, PTK_ERR_BAD_ARG, "no communicator: call ptk_comm_init");
+    int r = -1, w = 0, d = -1;
+    if (ncclCommCount(c->comm, &w) != ncclSuccess || ncclCommUserRank(c->comm, &r) != ncclSuccess || ncclCommCuDevice(c->comm, &d) != ncclSuccess)
+        return fail(c, PTK_ERR_RCCL, "ncclCommCount / ncclCommUserRank / ncclCommCuDevice failed");
+    if (rank) *rank = r;
+    if (world) *world = w;
+    if (comm_device) *comm_device = d;
     return PTK_OK;
 }
 

@@ -83,6 +83,8 @@ struct RenderParams {
     const float4* primary_rd;   // [H][W] its unit direction (valid with primary_hit)
     float* accum;               // [H][W][3] float RGB, rows bottom-up (mTotalImg)
     uint8_t* rgb8;              // [H][W][3] RGB8, rows bottom-up (mOutImg)
+    uint8_t* rgb8_host;         // the caller's page-locked hand-off buffer, device-visible (ptk_bind_out_image), or null
+    int rgb8_host_full;         // 1: every pixel is written there; 0: pixels whose cached camera ray misses are skipped (they hold 0)
     const uint32_t* exit_flag;  // holds the generation of the newest render an Exit() was aimed at (0: none)
     uint32_t exit_gen;          // this render's generation: its kernels stand down when *exit_flag >= exit_gen (Exit() cuts everything in flight)
     unsigned long long* stats;  // 7 counters (STATS variant only)

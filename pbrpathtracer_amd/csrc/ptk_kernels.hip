@@ -1693,13 +1693,42 @@ __global__ __launch_bounds__(PTK_BLOCK) void accumulate_kernel(const RenderParam
     }
     P.accum[accidx] = acc.x; P.accum[accidx + 1] = acc.y; P.accum[accidx + 2] = acc.z;
     float c3[3] = { acc.x / P.resolve_samples, acc.y / P.resolve_samples, acc.z / P.resolve_samples };
+    uint8_t b3[3];
 #pragma unroll
     for (int k = 0; k < 3; k++)
     {
         float x = c3[k];
         x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
         if (!(x == x)) x = 0.0f;
-        P.rgb8[accidx + k] = (uint8_t)(x * 255);
+        b3[k] = (uint8_t)(x * 255);
+        P.rgb8[accidx + k] = b3[k];
+    }
+    if (P.rgb8_host)
+    {
+        // The hand-off: straight into the caller's page-locked buffer, over PCIe.  A pixel that receives nothing AND holds
+        // nothing resolves to 0 whatever the sample count - it was written when the buffer was bound / reset and is
+        // skipped (four fifths of the C2 frame); one that holds light from before a camera move keeps dimming and is
+        // written.  Byte stores of single pixels crawl over the link (measured: 0.5 MB in 70 us), so a row of the quadrant
+        // - 8 pixels, 24 contiguous bytes - is gathered with lane shuffles and leaves as six dwords.
+        const bool skip_host = black && acc.x == 0.0f && acc.y == 0.0f && acc.z == 0.0f && !P.rgb8_host_full;
+        const uint32_t mine = (uint32_t)b3[0] | ((uint32_t)b3[1] << 8) | ((uint32_t)b3[2] << 16);
+        const unsigned long long row_live = (__ballot(!skip_host) >> (lane & ~7)) & 0xffull;     // this row's pixels that must be written
+        // dword d (0..5) of the row holds bytes 4d..4d+3 = pixels (4d)/3 .. (4d+3)/3; lanes 0..5 of each row write one each
+        const int d = lane & 7;
+        const int p0 = (4 * d) / 3, p1 = min(7, (4 * d + 3) / 3), sh = (4 * d) % 3;          // first pixel, last pixel, byte offset in the first
+        const uint32_t w0 = (uint32_t)__shfl((int)mine, (lane & ~7) + min(p0, 7)), w1 = (uint32_t)__shfl((int)mine, (lane & ~7) + p1);
+        // bytes of pixel p0 from offset sh, then pixel p0 + 1 (= p1 unless the dword lies within one pixel... it never does: 4 > 3)
+        const uint32_t word = (w0 >> (8 * sh)) | (w1 << (8 * (3 - sh)));
+        const bool aligned = (((size_t)P.width * 3) & 3) == 0 && (((uintptr_t)P.rgb8_host) & 3) == 0;
+        const int row_px = min(8, P.width - (px - (lane & 7)));                                // pixels of this row on the image (>= 1 here)
+        if (aligned && row_px == 8)
+        {
+            if (d < 6 && row_live != 0ull) *(uint32_t*)(P.rgb8_host + accidx - (size_t)(lane & 7) * 3 + d * 4) = word;
+        }
+        else if (!skip_host)
+        {
+            P.rgb8_host[accidx] = b3[0]; P.rgb8_host[accidx + 1] = b3[1]; P.rgb8_host[accidx + 2] = b3[2];
+        }
     }
 }
 

@@ -66,6 +66,7 @@ SYMBOLS = [
     "ptk_bvh_info", "ptk_bvh_layout", "ptk_upload_timing", "ptk_download_bvh", "ptk_probe_hits", "ptk_probe_primary_dirs", "ptk_probe_math", "ptk_probe_direct", "ptk_host_alloc", "ptk_host_free",
     "ptk_packed_floats", "ptk_packed_layout", "ptk_comm_unique_id", "ptk_comm_init", "ptk_comm_destroy",
     "ptk_gather_wait", "ptk_read_gathered", "ptk_gathered_device_ptr", "ptk_probe_pack", "ptk_probe_unpack",
+    "ptk_bind_out_image", "ptk_comm_info",
 ]
 
 
@@ -108,6 +109,8 @@ def load() -> C.CDLL:
     L.ptk_comm_unique_id.argtypes = [vp]
     L.ptk_comm_init.argtypes = [vp, vp, i32, i32]
     L.ptk_comm_destroy.argtypes = [vp]
+    L.ptk_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.ptk_bind_out_image.argtypes = [vp, vp]
     L.ptk_gather_wait.argtypes = [vp]
     L.ptk_read_gathered.argtypes = [vp, vp]
     L.ptk_gathered_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -301,6 +304,20 @@ class Context:
 
     def comm_destroy(self):
         self._chk(self.L.ptk_comm_destroy(self.h), "ptk_comm_destroy")
+
+    def comm_info(self) -> dict:
+        """rank / world / device as the library's own RCCL communicator reports them, and the context's HIP ordinal."""
+        r, w, d, cd = C.c_int32(-1), C.c_int32(0), C.c_int32(-1), C.c_int32(-1)
+        self._chk(self.L.ptk_comm_info(self.h, C.byref(r), C.byref(w), C.byref(d), C.byref(cd)), "ptk_comm_info")
+        return {"rank": r.value, "world": w.value, "comm_device": d.value, "ctx_device": cd.value}
+
+    def bind_out_image(self, out):
+        """ptk_bind_out_image: `out` = a C-contiguous uint8 [H, W, 3] array (kept alive by the caller) or None."""
+        if out is None:
+            self._chk(self.L.ptk_bind_out_image(self.h, None), "ptk_bind_out_image")
+            return
+        assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and out.size == self.width * self.height * 3
+        self._chk(self.L.ptk_bind_out_image(self.h, out.ctypes.data_as(C.c_void_p)), "ptk_bind_out_image")
 
     def gather_accum(self, root: int = 0, comm=None):
         self._chk(self.L.ptk_gather_accum(self.h, comm, root), "ptk_gather_accum")

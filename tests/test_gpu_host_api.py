@@ -259,6 +259,56 @@ def test_page_locked_handoff_buffer(tmp_path):
     assert frames[0].any() and np.array_equal(frames[0], frames[1])
 
 
+def test_bound_handoff_buffer_tracks_every_frame(tmp_path, oracle_mod):
+    """The interactive loop (main.cpp:3563-3618: one RenderFrame(), one glTexSubImage2D(texData)): SetOutImage binds the
+    caller's buffer (ptk_bind_out_image) and the accumulate kernel's 8-bit resolve lands in it directly - an ordinary
+    `new GLubyte[]`-like buffer is page-locked in place, a ptk_host_alloc one used as it is.  Whatever happens between
+    frames - camera moves that change which pixels are black for good, ResetImage, an Exit(), a new resolution - the
+    buffer holds exactly the device's resolved frame (and the oracle's) after every RenderFrame()."""
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
+    pts, scene, _ = S.build_config("C1", str(tmp_path), width=112, height=80, depth=4)
+    for pinned in (False, True):
+        pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(9); pt.SetCameraAperture(0.0)
+        W, H = pt.GetResolution()
+        out = pt.AllocOutImage() if pinned else np.full((H, W, 3), 77, np.uint8)       # (garbage in: the bind clears it)
+        pt.SetOutImage(out)
+        ctx = None
+        for frame in range(12):
+            if frame == 4:
+                pt.SetCamera((0.6, 0.2, -3.5), (-0.15, -0.05, 1.0), (0, 1, 0))       # other pixels miss the box now
+            if frame == 7:
+                pt.ResetImage()
+            if frame == 9:
+                pt.Exit()                                                              # (nothing in flight: must not disturb the next frame)
+            pt.RenderFrame()
+            assert pt.LastError() == ""
+            ctx = ctx or pt.context()
+            dev = np.zeros((H, W, 3), np.uint8)
+            ctx.L.ptk_resolve_rgb8(ctx.h, dev.ctypes.data)                               # into another buffer: a real copy of the device's frame
+            assert np.array_equal(np.asarray(out), dev), (pinned, frame)
+        assert np.asarray(out).any()
+        # the last frames against the oracle: 5 samples since the reset at frame 7
+        cam = camera_from_scene(scene); cam["aperture"] = 0.0
+        cam["pos"] = np.array([0.6, 0.2, -3.5], np.float32)
+        d = np.array([-0.15, -0.05, 1.0], np.float32); cam["dir"] = d / np.float32(np.sqrt((d * d).sum(dtype=np.float32)))
+        o = oracle_mod.Oracle(pt.StagedScene())
+        ocam = oracle_mod.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+        _, ref8 = o.render(ocam, W, H, pt.GetTraceDepth(), 0, 5, 9)
+        assert pt.GetSamples() == 5 and np.array_equal(np.asarray(out), ref8), pinned
+        # a new resolution: the caller reallocates its buffer and hands it over again (main.cpp:3425-3446)
+        pt.SetResolution((64, 48))
+        out2 = np.full((48, 64, 3), 5, np.uint8)
+        pt.SetOutImage(out2); pt.ResetImage(); pt.RenderFrame()
+        dev2 = np.zeros((48, 64, 3), np.uint8); ctx = pt.context(); ctx.L.ptk_resolve_rgb8(ctx.h, dev2.ctypes.data)
+        assert np.array_equal(out2, dev2) and out2.any()
+        pt.SetOutImage(None)
+        pt.RenderFrame()                                                               # unbound again: nothing may touch out2
+        assert np.array_equal(out2, dev2)
+        pt.close()
+        del out, out2
+
+
 @pytest.mark.parametrize("cfg,world", [("C1", 1), ("C2", 97), ("C3", 149), ("C4", 499), ("C5", 1999)])
 def test_full_size_spot_check_against_oracle(tmp_path, oracle_mod, cfg, world):
     """The BASELINE configs at their FULL size and sample count (persistent waves, live-quadrant list, two passes for

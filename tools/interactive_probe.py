@@ -7,6 +7,7 @@ from pbrpathtracer_amd.pathtracer import PathTracer
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 pts, scene, _ = S.build_config(cfg, tempfile.mkdtemp())
 pt = PathTracer(0); pt.LoadSceneFile(pts)
+if len(sys.argv) > 2 and sys.argv[2] == "pinhole" and scene.pinhole: pt.SetCameraAperture(0.0)      # as bench.py does (the .pts carries F = 1e9)
 W, H = pt.GetResolution()
 out = np.zeros((H, W, 3), np.uint8); pt.SetOutImage(out)
 for _ in range(5): pt.RenderFrame()
