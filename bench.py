@@ -17,18 +17,25 @@ packed RCCL gather (ptk_gather_accum: pack kernel -> grouped ncclSend/ncclRecv -
 step's trace kernel.
 
 Prints ONE JSON line on rank 0 (see the driver contract) including
-  roofline       the roof that bounds trace_kernel, chosen from the data: "valu" when the PMC-measured HBM traffic
-                 (profiles/traffic_<config>.json) is under 10 % of the HBM peak, else "hbm".  VALU: SURVEY 8(d4)'s
-                 algorithmic flops / ms_per_step vs the 157.3 TFLOP/s FP32 vector peak.  HBM: 8(d4)'s algorithmic
-                 bytes / launch duration - or, where the caches serve most of those (the rate asked exceeds what the
-                 counters saw leave the L2), the counter traffic itself.  Both sets of figures stay beside the head,
-                 with the offline instruction-class bounds of the VALU pipe's occupancy (profiles/r02/).
+  roofline       the roof that bounds trace_kernel, chosen from the data: "valu" when the PMC-measured traffic that left
+                 the L2 (profiles/traffic_<config>.json - used only while the kernel sources still hash to what was
+                 profiled, else `traffic` is null and says so) is under 10 % of the HBM peak, else "l2_miss_fabric"
+                 (FETCH_SIZE counts Infinity-Cache hits too: not all of it reached HBM).  VALU: SURVEY 8(d4)'s
+                 algorithmic flops / ms_per_step vs the 157.3 TFLOP/s FP32 vector peak.
+  parity         image parity beside the number: after the timed region one step is rendered again from a
+                 reset accumulator on the tiles of one rank of a K-way split and the CPU oracle renders the same tiles -
+                 per-channel RMSE of the mean image, fraction of accumulator words that agree exactly, pixel count.
+  value_contracted  the same step with the contracted build of the trace kernels (ptk_set_option "contract" 2), its own
+                 roofline fraction and its own parity against the oracle (tolerance 1e-3 RMSE); `value` is the exact build.
+  interactive    (N = 1; C2, C4) the reference's own use: one RenderFrame() per loop iteration + hand-off into the caller's
+                 buffer (main.cpp:3563-3618, :3026-3029) - ms per RenderFrame() with and without the hand-off, launches per frame.
   cpu_baseline   both CPU modes of SURVEY 8(d5), timed on this box's host cores on a bounded sample of the same
                  workload (N = 1 only): the reference's own OpenMP path as shipped (oracle/_ref, built from
-                 /root/reference by __graft_entry__.build()) and the oracle port with a per-path RNG on all cores;
-                 `value` is the FASTER of the two (the >= 10x target is judged against it).
-  other_configs  (N = 1, default run) the BVH-walk configs C3, C4 (2 steps each) and C5 (1 step) after the timed headline, so the
-                 driver's line carries the BVH-walk kernel's Msamples/s and roofline too.
+                 /root/reference by __graft_entry__.build()) and the oracle port with a per-path RNG on all cores, timed
+                 at 1 and at 16 samples per call; `value` is the FASTEST (the >= 10x target is judged against it).
+  other_configs  N = 1, default run: the BVH-walk configs C3, C4 (3 steps each) and C5 (2 steps) after the timed headline,
+                 numbers and short keys only.  N > 1 with --with-c5 (implied by --gpus 8): BASELINE config 5 as stated -
+                 C5 tile-split over the ranks, the exchange inside the timed region, gathered-image checksum.
 """
 from __future__ import annotations
 
@@ -73,6 +80,10 @@ def parse_args(argv=None):
                     help="gloo = REHEARSAL of the N>1 control flow where ranks must share one GPU (RCCL refuses that): the exchange "
                          "then goes through host copies in the library's packing order; the numbers mean nothing")
     ap.add_argument("--share-of", type=int, default=0, help="rehearsal: render only rank 0's tiles of an N-rank split on this one GPU")
+    ap.add_argument("--with-c5", action="store_true", help="N > 1: append BASELINE config 5 (C5 tile-split over the ranks, 1 step) as other_configs.C5; implied by --gpus 8")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check beside the number")
+    ap.add_argument("--no-contracted", action="store_true", help="skip the contracted-build measurement")
+    ap.add_argument("--no-interactive", action="store_true", help="skip the RenderFrame()-per-iteration measurement")
     return ap.parse_args(argv)
 
 
@@ -116,8 +127,17 @@ def sha256_of(path: str):
         return None
 
 
-def cpu_baseline(scene, name: str, budget_s: float = 10.0):
-    """Both CPU modes of SURVEY.md 8(d5) on a bounded sample of the same workload (whole frames of 1 spp)."""
+def kernel_source_sha256() -> str:
+    """What the committed counter files are tied to: the sources of the kernels that ran."""
+    h = hashlib.sha256()
+    for f in ("ptk_kernels.hip", "ptk_device.h"):
+        with open(os.path.join(ROOT, "pbrpathtracer_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def cpu_baseline(scene, name: str, budget_s: float = 8.0):
+    """Both CPU modes of SURVEY.md 8(d5) on a bounded sample of the same workload (whole frames)."""
     import ctypes
     from oracle import ref_binding
     w, h = scene.width, scene.height
@@ -144,7 +164,8 @@ def cpu_baseline(scene, name: str, budget_s: float = 10.0):
     else:
         print("bench.py: oracle/_ref/libptref.so is ABSENT (it is built from /root/reference by __graft_entry__.build() in the "
               "build container): the reference-as-shipped CPU mode cannot be timed; reporting the oracle port only", file=sys.stderr)
-    # (2) the "fixed" mode: our own C restatement (oracle/pt_oracle.c), per-path counter RNG, all cores
+    # (2) the "fixed" mode: our own C restatement (oracle/pt_oracle.c), per-path counter RNG, all cores, 16 x 16 tiles dealt
+    #     dynamically - timed with 1 sample per call (what a RenderFrame() of the reference is) and with 16 per call
     from oracle import oracle_binding as OB
     from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
     from pbrpathtracer_amd import scenes as S
@@ -159,20 +180,92 @@ def cpu_baseline(scene, name: str, budget_s: float = 10.0):
     o = OB.Oracle(arrays)
     ocam = OB.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
     cores = os.cpu_count() or 1
-    total = np.zeros((h, w, 3), np.float32)
-    frames, sec = 0, 0.0
-    while sec < budget_s and frames < 64:
-        t0 = time.time()
-        o.render(ocam, w, h, scene.trace_depth, frames, 1, 1, total=total, threads=cores, want_rgb8=False)
-        sec += time.time() - t0
-        frames += 1
-    modes["port"] = {"value": round(w * h * frames / sec / 1e6, 4), "unit": "Msamples/s", "cores": int(cores), "kind": "port",
-                     "sample": f"{frames} frames (1 spp each) of {name} at {w}x{h}, depth {scene.trace_depth}; oracle/pt_oracle.c, "
-                               f"per-path counter RNG (no shared engine), OpenMP on all cores"}
+    for per_call, key in ((1, "port"), (16, "port_16spp")):
+        total = np.zeros((h, w, 3), np.float32)
+        calls, sec = 0, 0.0
+        while sec < budget_s * 0.6 and calls < 64:
+            t0 = time.time()
+            o.render(ocam, w, h, scene.trace_depth, calls * per_call, per_call, 1, total=total, threads=cores, want_rgb8=False)
+            sec += time.time() - t0
+            calls += 1
+        modes[key] = {"value": round(w * h * per_call * calls / sec / 1e6, 4), "unit": "Msamples/s", "cores": int(cores), "kind": "port",
+                      "sample": f"{calls} calls of {per_call} spp of {name} at {w}x{h}, depth {scene.trace_depth}; oracle/pt_oracle.c, per-path "
+                                f"counter RNG (no shared engine), OpenMP on all cores, 16x16 tiles dealt dynamically"}
     best = max(modes.values(), key=lambda m: m["value"])
     out = dict(best)
-    out["modes"] = modes
+    out["modes"] = {k: {kk: vv for kk, vv in v.items() if kk in ("value", "cores", "kind")} for k, v in modes.items()}
+    if "reference" in modes:
+        out["reference_binary_sha256"] = modes["reference"]["binary_sha256"]
+        out["reference_recipe_sha256"] = modes["reference"]["recipe_sha256"]
     out["reference_missing"] = "reference" not in modes
+    return out
+
+
+def parity_check(pt, ctx, scene, W, H, D, spp, seed, levels):
+    """Image parity beside the number: one step from a reset accumulator on the tiles of one rank of a K-way
+    split (K sized for ~3 M samples), against the CPU oracle on the same tiles.  Per contract level: per-channel RMSE of the
+    mean image, fraction of accumulator words equal bit for bit, pixels compared."""
+    from oracle import oracle_binding as OB
+    from pbrpathtracer_amd.pathtracer import camera_from_scene
+    from pbrpathtracer_amd.distributed import tile_owner_mask, owned_tile_count
+    tiles = owned_tile_count(W, H, 0, 1)
+    budget = 1.0e6 if len(pt.StagedScene()["material"]) > 300000 else 3.0e6      # (the oracle walks a 1 M-triangle tree ~4x slower)
+    K = max(1, int(np.ceil(tiles * 256.0 * spp / budget)))
+    r = K // 3
+    cam = camera_from_scene(scene)
+    if scene.pinhole:
+        cam["aperture"] = 0.0
+    t0 = time.time()
+    o = OB.Oracle(pt.StagedScene())
+    ocam = OB.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+    ref, _ = o.render(ocam, W, H, D, 0, spp, seed, rank=r, world=K, want_rgb8=False)
+    o.close()
+    t_oracle = time.time() - t0
+    mask = tile_owner_mask(W, H, r, K)[::-1]                      # accumulator rows are bottom-up
+    out = {}
+    for level in levels:
+        ctx.set_option("contract", level)
+        ctx.set_tile(r, K)
+        ctx.reset()
+        ctx.render(0, spp, seed)
+        got = ctx.read_accum()
+        d = (got[mask].astype(np.float64) - ref[mask].astype(np.float64)) / spp
+        rmse = np.sqrt((d ** 2).mean(axis=0))
+        out[level] = {"rmse": [float(f"{x:.3e}") for x in rmse], "exact_fraction": round(float(np.mean(got[mask] == ref[mask])), 6),
+                      "pixels": int(mask.sum()), "spp": int(spp), "split": f"rank {r} of {K}", "oracle_s": round(t_oracle, 2),
+                      "tolerance_rmse": 1e-3, "ok": bool((rmse <= 1e-3).all() and np.isfinite(got).all())}
+    ctx.set_option("contract", 0)
+    return out
+
+
+def interactive_probe(pt, ctx, W, H, frames=200):
+    """The reference's own caller: one RenderFrame() per loop iteration followed by the hand-off of texData
+    (PathTracerLoop main.cpp:3563-3618, glTexSubImage2D :3026-3029)."""
+    out = {}
+    pinned = pt.AllocOutImage()
+    pt.SetOutImage(pinned); pt.ResetImage()
+    for _ in range(10):
+        pt.RenderFrame()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        pt.RenderFrame()
+    out["with_handoff_ms"] = round((time.perf_counter() - t0) / frames * 1e3, 4)
+    out["launches_per_frame"] = int(ctx.last_render_ms()[1])
+    host = np.array(pinned)
+    dev = ctx.resolve_rgb8()                    # into another buffer: a real copy of the device's resolved frame
+    pt.SetOutImage(None)
+    for _ in range(10):
+        pt.RenderFrame()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        pt.RenderFrame()
+    ctx.synchronize()
+    out["ms_per_RenderFrame"] = round((time.perf_counter() - t0) / frames * 1e3, 4)
+    out["handoff"] = "8-bit resolve written by accumulate_kernel straight into the caller's page-locked buffer (ptk_bind_out_image); no copy command"
+    out["frame_matches_device"] = bool(np.array_equal(host, dev)) and bool(host.any())
+    out["Msamples_per_s_with_handoff"] = round(W * H / out["with_handoff_ms"] / 1e3, 1)
+    del pinned
     return out
 
 
@@ -216,6 +309,7 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
 
     # ---- exchange step ------------------------------------------------------------------------------
     exchange, host_accum = None, None
+    comm = {"rccl_ranks": None, "devices": [local_rank]}
     if world > 1 and rehearsal:
         host_accum = torch.zeros(H * W * 3, dtype=torch.float32)
         exchange = HostPackedExchange(host_accum, W, H, dst=0)
@@ -230,6 +324,17 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
         if args.share_of > 1 and world == 1:
             ctx.set_tile(0, 1)
         exchange = NativeExchange(ctx, root=0)
+        info = ctx.comm_info()                  # what the library's own communicator reports - not torch's WORLD_SIZE
+        comm["rccl_ranks"] = info["world"]
+        comm["devices"] = [info["comm_device"]]
+    if world > 1:
+        # the distinct HIP ordinals the ranks render on (one node: N ranks must mean N devices)
+        box = [None] * world
+        dist.all_gather_object(box, (comm["devices"][0], comm["rccl_ranks"]))
+        comm["devices"] = sorted({int(d) for d, _ in box})
+        ranks_seen = {r for _, r in box}
+        if len(ranks_seen) == 1 and comm["rccl_ranks"] is None:
+            comm["rccl_ranks"] = None
     every = max(1, args.exchange_every)
     exchanges = [0]
 
@@ -250,16 +355,28 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
             dist.barrier()
             torch.cuda.synchronize()
 
-    first = 0
-    for i in range(warmup):
-        step(first, i, i == warmup - 1); first += spp
-    fence()
-    exchanges[0] = 0
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(first, i, i == steps - 1); first += spp
-    fence()
-    elapsed = time.perf_counter() - t0
+    first = [0]
+
+    def timed(n_warm, n_steps):
+        """n_warm untimed steps, then exactly n_steps between two fences; max over ranks; returns seconds"""
+        for i in range(n_warm):
+            step(first[0], i, i == n_warm - 1); first[0] += spp
+        fence()
+        exchanges[0] = 0
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(first[0], i, i == n_steps - 1); first[0] += spp
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    elapsed = timed(warmup, steps)
+    timed_exchanges = exchanges[0]
+    checksum = None
     if world > 1 and exchange is not None:
         # property check of the exchange: the gathered image holds exactly what the ranks hold together
         mine = ctx.read_accum()
@@ -271,14 +388,20 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
             got = exchange.result()
             got = float(np.asarray(got, dtype=np.float64).sum()) if not hasattr(got, "double") else float(got.double().sum().item())
             ok = abs(got - float(part.item())) <= 1e-9 * max(1.0, abs(got))
-            print(f"bench.py: gathered-image checksum {'OK' if ok else 'MISMATCH'} ({got:.6f} vs {float(part.item()):.6f}), "
-                  f"exchange mode {exchange.mode}, {exchanges[0]} exchanges in the timed region", file=sys.stderr)
+            checksum = {"gathered": got, "sum_of_ranks": float(part.item()), "ok": bool(ok)}
+            print(f"bench.py: {name} gathered-image checksum {'OK' if ok else 'MISMATCH'} ({got:.6f} vs {float(part.item()):.6f}), "
+                  f"exchange mode {exchange.mode}, {timed_exchanges} exchanges in the timed region", file=sys.stderr)
             if not ok:
                 sys.exit(5)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    # ---- the contracted build of the trace kernels on the same steps (every rank; value stays the exact build's) ----
+    contracted = None
+    if not args.no_contracted and "contract=" not in args.opts:
+        ctx.set_option("contract", 2)
+        n_c = max(1, min(steps, 100))
+        el_c = timed(min(warmup, 2), n_c)
+        ctx.set_option("contract", 0)
+        contracted = {"level": 2, "steps": n_c, "elapsed": el_c}
 
     # kernel time per launch, measured live with HIP events recorded on the kernels' own stream around each launch
     # (trace_kernel and accumulate_kernel separately), launch by launch, un-overlapped: in the timed loop above the
@@ -287,10 +410,10 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
     ev_ms, acc_ms = [], []
     ctx.set_option("overlap", 0)
     for _ in range(max(1, min(steps, 3))):
-        ctx.render(first, spp, args.seed); first += spp
+        ctx.render(first[0], spp, args.seed); first[0] += spp
         t_ms, a_ms = ctx.last_kernel_ms()
         ev_ms.append(t_ms); acc_ms.append(a_ms)
-        passes = max(1, ctx.last_render_ms()[1] // 2)          # trace_kernel launches per step (the sample buffer bounds a launch)
+        passes = max(1, ctx.last_render_ms()[1] // 3)          # trace_kernel launches per step (the sample buffer bounds a launch)
     ctx.set_option("overlap", 1)
     for kv in args.opts.split(","):
         if kv.startswith("overlap="):
@@ -324,59 +447,55 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
     # that many of the survey's 32-B node records / 30-flop box tests
     d4_bytes = 27.0 + per["node_visits"] * node_boxes * 32 + per["tri_tests"] * 36 + per["hits_shaded"] * (104 + 48) + per["tex_fetches"] * 4
     d4_flops = per["node_visits"] * node_boxes * 30 + per["tri_tests"] * 50 + per["hits_shaded"] * 250
+    # what the kernels really ask of the memory system: a 64-B BVH4 node, a 48-B triangle record, 112-B shading + 96-B material
+    req_bytes = 27.0 + 16.0 * live_fraction + per["node_visits"] * 64 + per["tri_tests"] * 48 + per["hits_shaded"] * (112 + 96) + per["tex_fetches"] * 4
     step_samples = float(W) * H * spp                                  # whole job per step (all ranks)
     step_s = ms_per_step * 1e-3
     valu_tflops = d4_flops * step_samples / step_s / 1e12 / world      # per GPU
     d4_gbps = d4_bytes * step_samples / step_s / 1e9 / world
     kernel_ms = float(np.mean(ev_ms))
-    traffic, traffic_src, cache = None, None, None
+    traffic, traffic_src, cache, traffic_note = None, None, None, None
     traffic_file = os.path.join(ROOT, "profiles", f"traffic_{name}.json")
     if os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
             if tr.get("spp") == spp and tr.get("n_gpus", 1) == world:
-                traffic = tr["hbm_bytes_per_launch"] * passes            # per step = per launch x launches per step
-                traffic_src = tr.get("source")
-                cache = tr.get("cache")
+                if tr.get("kernel_source_sha256") == kernel_source_sha256():
+                    traffic = tr["hbm_bytes_per_launch"] * passes        # per step = per launch x launches per step
+                    traffic_src = tr.get("source")
+                    cache = tr.get("cache")
+                else:
+                    traffic_note = ("profiles/traffic_%s.json was collected for other kernel sources (its kernel_source_sha256 differs "
+                                    "from pbrpathtracer_amd/csrc/ptk_kernels.hip + ptk_device.h as built): not used" % name)
         except Exception:
             pass
     counter_gbps = traffic / (kernel_ms * 1e-3) / 1e9 if traffic is not None else None
-    # which roof bounds the kernel: HBM only if the counters see at least a tenth of the HBM peak
-    if counter_gbps is not None:
-        bound = "hbm" if counter_gbps >= 0.1 * HBM_PEAK_GBS else "valu"
-    else:
-        bound = "valu"                          # no counter file for this shape: cache-resident scenes are the rule here
-    if bound == "hbm":
-        # The algorithmic bytes of 8(d4) are what the rays ask of the memory system.  Where the caches serve most of them
-        # (asked > what the counters saw leave the L2) the distance to the HBM roof is what the counters saw, not what
-        # was asked: a fraction above 1 would say nothing.
-        if d4_gbps > counter_gbps:
-            head = {"bound": "hbm", "achieved": round(counter_gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(counter_gbps / HBM_PEAK_GBS, 4),
-                    "achieved_basis": "counters: bytes that left the L2 (FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included) - the "
-                                      "algorithmic bytes (roofline.hbm.achieved_GBps) are mostly served by the caches"}
-        else:
-            head = {"bound": "hbm", "achieved": round(d4_gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d4_gbps / HBM_PEAK_GBS, 4),
-                    "achieved_basis": "algorithmic bytes of SURVEY 8(d4)"}
+    # which roof bounds the kernel: the memory side only if the counters see at least a tenth of the HBM peak leave the L2
+    if counter_gbps is not None and counter_gbps >= 0.1 * HBM_PEAK_GBS:
+        # FETCH_SIZE counts what left the L2, Infinity-Cache hits included: an upper bound of what HBM saw
+        head = {"bound": "l2_miss_fabric", "achieved": round(counter_gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(counter_gbps / HBM_PEAK_GBS, 4),
+                "achieved_basis": "counters: bytes that left the L2 (FETCH_SIZE x2 + WRITE_SIZE), Infinity-Cache hits included - an upper bound "
+                                  "of the HBM traffic, priced against the HBM peak"}
     else:
         head = {"bound": "valu", "achieved": round(valu_tflops, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4)}
     roofline = dict(head)
     roofline.update({
-        "traffic": traffic, "traffic_source": traffic_src,
+        "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
         "kernel": "trace_kernel<FLAT>" if flat else "trace_kernel<BVH>", "kernel_ms_isolated": round(kernel_ms, 4),
         "trace_launches_per_step": passes,
         "accumulate_kernel_ms": round(float(np.mean(acc_ms)), 4),
-        "computed_from": "ms_per_step (timed region; consecutive launches overlap their tails, so a step is shorter than an isolated launch)",
+        "computed_from": "ms_per_step (timed region; consecutive launches overlap their tails - profiles/r03/overlap_trace_C2.json - so a step is shorter than an isolated launch)",
         "valu": {"flops_per_sample": round(d4_flops, 1), "achieved_TFLOPs": round(valu_tflops, 2), "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4),
-                 "note": "algorithmic flops of SURVEY 8(d4): 30 per box test, 50 per triangle test, 250 per shaded hit; the peak counts an FMA "
-                         "as 2 flops, which the parity contract (-ffp-contract=off) forbids, so 0.5 is this fraction's ceiling; calibrated "
-                         "issue costs per instruction class: profiles/r02/valu_calibration.json"},
-        "hbm": {"algorithmic_bytes_per_sample": round(d4_bytes, 1), "achieved_GBps": round(d4_gbps, 1), "frac": round(d4_gbps / HBM_PEAK_GBS, 4),
+                 "note": "SURVEY 8(d4) flops: 30 / box test, 50 / triangle test, 250 / shaded hit; the peak counts an FMA as 2 flops, which the "
+                         "exact build (-ffp-contract=off) forgoes: 0.5 is its ceiling (value_contracted lifts that)"},
+        "hbm": {"algorithmic_bytes_per_sample": round(d4_bytes, 1), "requested_bytes_per_sample": round(req_bytes, 1),
+                "achieved_GBps": round(d4_gbps, 1), "frac": round(d4_gbps / HBM_PEAK_GBS, 4),
                 "counter_GBps": round(counter_gbps, 1) if counter_gbps is not None else None,
                 "counter_frac": round(counter_gbps / HBM_PEAK_GBS, 4) if counter_gbps is not None else None,
                 "cache": cache,
-                "note": "algorithmic bytes of SURVEY 8(d4) (32 B per box, 36 B per triangle, 152 B per hit, 27 B per sample); a fraction "
-                        "above 1 means the bytes are served by caches, not HBM - the counter figures say how much HBM saw"},
+                "note": "algorithmic = SURVEY 8(d4) record sizes (32 B / box, 36 B / triangle, 152 B / hit, 27 B / sample); requested = the "
+                        "kernels' own records (64-B BVH4 node, 48-B triangle, 208 B / hit, 16-B sample write); > 1 means served by caches"},
         "per_sample": {k: round(v, 3) for k, v in per.items()},
         "live_fraction": round(live_fraction, 4),
         "kernel_variant": "FLAT (no BVH walk, scalar triangle loads)" if flat else f"BVH{node_boxes} walk, {64}-byte nodes",
@@ -385,24 +504,26 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
                                   "shade": round(stats["shade_lanes"] / max(1, stats["shade_wave_execs"]) / 64.0, 3),
                                   "camera": round(stats["gen_lanes"] / max(1, stats["gen_wave_execs"]) / 64.0, 3)},
     })
-    sq_file = os.path.join(ROOT, "profiles", "r02", f"pmc_sq_trace_kernel_{name}.json")
-    if os.path.exists(sq_file) and world == 1:
-        try:
-            sq = json.load(open(sq_file))
-            roofline["valu"]["pipe_busy_bounds_offline"] = [sq.get("valu_pipe_busy_low"), min(1.0, sq.get("valu_pipe_busy_high", 1.0))]
-            roofline["valu"]["lane_utilisation_offline"] = sq.get("lane_utilisation")
-            roofline["valu"]["offline_source"] = ("profiles/r02/pmc_sq_trace_kernel_%s.json: instruction-class counters of this command x the "
-                                                  "calibrated issue cost of each class (lower bound: every unclassified instruction full rate; "
-                                                  "upper: half rate)" % name)
-        except Exception:
-            pass
+    sq = None
+    for rdir in ("r03", "r02"):
+        sq_file = os.path.join(ROOT, "profiles", rdir, f"pmc_sq_trace_kernel_{name}.json")
+        if os.path.exists(sq_file) and world == 1:
+            try:
+                sq = json.load(open(sq_file))
+                if rdir == "r03" and sq.get("kernel_source_sha256") != kernel_source_sha256():
+                    sq = None
+                    continue
+                roofline["valu"]["pipe_busy_bounds_offline"] = [sq.get("valu_pipe_busy_low"), min(1.0, sq.get("valu_pipe_busy_high", 1.0))]
+                roofline["valu"]["lane_utilisation_offline"] = sq.get("lane_utilisation")
+                roofline["valu"]["offline_source"] = f"profiles/{rdir}/pmc_sq_trace_kernel_{name}.json" + ("" if rdir == "r03" else " (an earlier round's kernels)")
+                break
+            except Exception:
+                pass
     if not flat:
         # the walk's own ceiling: node + triangle records gathered per CU per second vs the dependent-gather rate the
         # chip sustains for 64-byte records at this occupancy (tools/microbench/gather_bench.hip)
         rec = (per["node_visits"] + per["tri_tests"] * 0.75) * step_samples / step_s / world / 256.0 / 1e9
-        roofline["gather"] = {"records64_per_s_per_cu_G": round(rec, 4),
-                              "note": "64-byte-record equivalents (a 48-B triangle record = 0.75) fetched per CU; ceiling: "
-                                      "profiles/r02/gather_ceiling.json"}
+        roofline["gather"] = {"records64_per_s_per_cu_G": round(rec, 4), "ceiling_source": "profiles/r02/gather_ceiling.json"}
     out = {
         "metric": "Msamples/s (pixels*spp/s)", "value": round(value, 2), "unit": "Msamples/s",
         "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -412,17 +533,65 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
         "config": {"workload": WORKLOADS[name], "name": name, "width": W, "height": H, "max_depth": D, "spp_per_step": spp,
                    "triangles": ntri, "bvh_nodes": nodes, "bvh_depth": depth,
                    "parallelism": f"tile-split x{world}" if world > 1 else "single GPU",
+                   "rccl_ranks": comm["rccl_ranks"], "devices": comm["devices"],
                    "exchange": ((("native packed RCCL gather (ptk_gather_accum: each rank's owned tiles, 1/N of the float accumulator, "
                                   "ncclSend/ncclRecv to rank 0)" if not rehearsal else "REHEARSAL: packed gather over gloo through host copies")
                                  + f", every {every} steps and after the last, overlapped with the next step's trace kernel")
                                 if exchange is not None else "none"),
                    "exchange_every": every if exchange is not None else None,
-                   "exchanges_in_timed_region": exchanges[0] if exchange is not None else 0},
+                   "exchanges_in_timed_region": timed_exchanges if exchange is not None else 0,
+                   "gathered_checksum": checksum},
         "roofline": roofline,
         "host": {"scene_gen_s": round(t_gen, 3), "scene_load_bvh_upload_s": round(t_load, 3)},
     }
+    if contracted is not None:
+        v_c = float(W) * H * spp * contracted["steps"] / contracted["elapsed"] / 1e6
+        out["value_contracted"] = {"value": round(v_c, 2), "unit": "Msamples/s", "ms_per_step": round(contracted["elapsed"] / contracted["steps"] * 1e3, 4),
+                                   "steps": contracted["steps"], "over_exact": round(v_c / value, 4),
+                                   "build": "trace kernels with -ffp-contract=fast + 1-ulp v_rcp / v_sqrt / v_rsq (ptk_set_option contract=2)",
+                                   "roofline_frac": round(valu_tflops * (v_c / value) / VALU_PEAK_TFLOPS, 4) if head["bound"] == "valu" else None}
+    # ---- image parity beside the number (rank 0; the other ranks wait at the next rendezvous) ----------------------------
+    if not args.no_parity:
+        try:
+            levels = [0] + ([2] if contracted is not None else [])
+            ctx.set_tile(0, 1)
+            par = parity_check(pt, ctx, scene, W, H, D, spp, args.seed, levels)
+            ctx.set_tile(rank, world)
+            out["parity"] = par[0]
+            if 2 in par and "value_contracted" in out:
+                out["value_contracted"]["parity"] = {k: par[2][k] for k in ("rmse", "exact_fraction", "pixels", "ok")}
+        except Exception as e:
+            out["parity"] = {"error": f"{type(e).__name__}: {e}"}
+    # ---- the interactive loop (N = 1): RenderFrame() per iteration + hand-off ------------------------------------------
+    if world == 1 and not args.no_interactive and name in ("C2", "C4") and not args.opts and args.share_of <= 1:
+        try:
+            out["interactive"] = interactive_probe(pt, ctx, W, H)
+        except Exception as e:
+            out["interactive"] = {"error": f"{type(e).__name__}: {e}"}
     pt.close()
     return out, scene
+
+
+def short(o):
+    """numbers and short keys of a measure() result, for other_configs (the driver keeps only the tail of the line)"""
+    r = o["roofline"]
+    d = {"value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"], "n_gpus": o["n_gpus"],
+         "traced_samples_per_s": o["traced_samples_per_s"],
+         "workload": o["config"]["workload"], "triangles": o["config"]["triangles"], "bvh_nodes": o["config"]["bvh_nodes"],
+         "roofline": {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+                      "traffic": r["traffic"], "kernel_ms_isolated": r["kernel_ms_isolated"], "launches_per_step": r["trace_launches_per_step"],
+                      "valu_frac": r["valu"]["frac"], "lane_utilisation_offline": r["valu"].get("lane_utilisation_offline"),
+                      "l2_hit_rate": (r["hbm"]["cache"] or {}).get("l2_hit_rate") if r["hbm"].get("cache") else None,
+                      "counter_GBps": r["hbm"]["counter_GBps"], "per_sample": r["per_sample"], "simd_lane_utilisation": r["simd_lane_utilisation"]},
+         "parity": o.get("parity"), "host": o["host"]}
+    if "value_contracted" in o:
+        vc = o["value_contracted"]
+        d["value_contracted"] = {k: vc.get(k) for k in ("value", "over_exact", "roofline_frac", "parity")}
+    if "interactive" in o:
+        d["interactive"] = o["interactive"]
+    if o["n_gpus"] > 1:
+        d["config"] = {k: o["config"][k] for k in ("parallelism", "rccl_ranks", "devices", "exchanges_in_timed_region", "gathered_checksum")}
+    return d
 
 
 def main():
@@ -464,16 +633,26 @@ def main():
             out["gpu_over_cpu"] = round(out["value"] / base["value"], 1) if base["value"] > 0 else None
         except Exception as e:  # the baseline is reported, never required
             out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
-    if rank == 0 and world == 1 and not args.no_other_configs and args.config == "C2" and not args.opts:
-        others = {}
-        for name, k in (("C3", 2), ("C4", 2), ("C5", 1)):
+    others = {}
+    if world == 1 and not args.no_other_configs and args.config == "C2" and not args.opts:
+        # the BVH-walk configs at their full BASELINE size, through the identical code path (numbers + short keys only)
+        for name, k in (("C3", 3), ("C4", 3), ("C5", 2)):
             try:
                 o, _ = measure(name, args, 0, 1, local_rank, k, 1, headline=False)
-                others[name] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": k, "warmup": 1,
-                                "traced_samples_per_s": o["traced_samples_per_s"], "config": o["config"], "roofline": o["roofline"],
-                                "host": o["host"]}
+                others[name] = short(o)
             except Exception as e:
                 others[name] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+    elif world > 1 and (args.with_c5 or world == 8) and args.config != "C5":
+        # BASELINE config 5 as stated: the 1 M-triangle frame tile-split over the ranks, 1024 spp per step, the exchange
+        # inside the timed region (after the last step), gathered-image checksum - every rank runs it
+        try:
+            o, _ = measure("C5", args, rank, world, local_rank, 1, 1, headline=False)
+            if rank == 0:
+                others["C5"] = short(o)
+        except Exception as e:
+            if rank == 0:
+                others["C5"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and others:
         out["other_configs"] = others
     if world > 1:
         dist.barrier()

@@ -747,52 +747,65 @@ void orc_render(const orc_scene* s, const orc_camera* cam, int W, int H, int D,
                 float* total, uint8_t* rgb8, int threads)
 {
     frame_t f; frame_setup(cam, W, H, &f);
-    int tiles_x = (W + ORC_TILE - 1) / ORC_TILE;
+    int tiles_x = (W + ORC_TILE - 1) / ORC_TILE, tiles_y = (H + ORC_TILE - 1) / ORC_TILE;
     if (world < 1) world = 1;
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
+#endif
+    /* the rows' primary directions first (each row is an incremental walk from its first column, :782-785, :814) ... */
+    float* dirs_all = (float*)malloc((size_t)W * H * 3 * sizeof(float));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads)
+#endif
+    for (int i = 0; i < H; i++) primary_row(&f, W, i, dirs_all + (size_t)i * W * 3);
+    /* ... then the pixels, dealt to the threads as 16 x 16 tiles (the reference deals whole rows to its workers, :777: with
+     * hundreds of threads and a frame whose lit pixels sit in a band of rows that leaves most of them idle; the result
+     * of a pixel does not depend on who computes it) */
+#ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
 #endif
-    for (int i = 0; i < H; i++)                                                /* :777 */
+    for (int t = 0; t < tiles_x * tiles_y; t++)
     {
-        float* dirs = (float*)malloc((size_t)W * 3 * sizeof(float));
-        primary_row(&f, W, i, dirs);
-        for (int j = 0; j < W; j++)                                            /* :783 */
+        const int ty = t / tiles_x, tx = t % tiles_x;
+        const int tile = ty * tiles_x + (tx + 3 * ty) % tiles_x;    /* rows rotated by 3 tiles: diagonal ownership */
+        if (tile % world != rank) continue;
+        for (int i = ty * ORC_TILE; i < (ty + 1) * ORC_TILE && i < H; i++)     /* :777 */
         {
-            int ty = i / ORC_TILE, tx = j / ORC_TILE;
-            int tile = ty * tiles_x + (tx + 3 * ty) % tiles_x;      /* rows rotated by 3 tiles: diagonal ownership */
-            if (tile % world != rank) continue;
-            uint32_t pkey = pixel_key(seed, (uint32_t)(i * W + j));
-            size_t px = ((size_t)(H - 1 - i) * W + j) * 3;                     /* :796 bottom-up */
-            v3 acc = ld3(total + px);
-            v3 rayDir0 = ld3(dirs + j * 3);
-            for (uint32_t k = 0; k < spp; k++)
+            const float* dirs = dirs_all + (size_t)i * W * 3;
+            for (int j = tx * ORC_TILE; j < (tx + 1) * ORC_TILE && j < W; j++) /* :783 */
             {
-                rng_t rng; rng_init(&rng, pkey, first_sample + k);
-                v3 camPos = f.pos;                                             /* :787 */
-                v3 focalPoint = add(camPos, muls(rayDir0, cam->focal_dist));   /* :788 */
-                float r1 = rnd(&rng), r2 = rnd(&rng), off[2];
-                orc_sample_circle(r1, r2, off);
-                off[0] = off[0] * cam->aperture; off[1] = off[1] * cam->aperture;   /* :789 */
-                camPos = add(camPos, add(muls(f.right, off[0]), muls(f.up, off[1])));   /* :790 */
-                v3 rayDir = normalize(sub(focalPoint, camPos));                /* :791 */
-                v3 color = trace(s, camPos, rayDir, D, &rng);                  /* :793 */
-                acc = add(acc, color);                                         /* :798-800 */
-            }
-            total[px] = acc.x; total[px + 1] = acc.y; total[px + 2] = acc.z;
-            if (rgb8)
-            {
-                float ns = (float)(first_sample + spp);                        /* (float)mSamples */
-                float c[3] = { acc.x / ns, acc.y / ns, acc.z / ns };
-                for (int k = 0; k < 3; k++)
+                uint32_t pkey = pixel_key(seed, (uint32_t)(i * W + j));
+                size_t px = ((size_t)(H - 1 - i) * W + j) * 3;                 /* :796 bottom-up */
+                v3 acc = ld3(total + px);
+                v3 rayDir0 = ld3(dirs + j * 3);
+                for (uint32_t k = 0; k < spp; k++)
                 {
-                    float x = c[k];
-                    x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);               /* glm::clamp; NaN -> NaN */
-                    if (!(x == x)) x = 0.0f;
-                    rgb8[px + k] = (uint8_t)(x * 255);                         /* :810-812 truncation */
+                    rng_t rng; rng_init(&rng, pkey, first_sample + k);
+                    v3 camPos = f.pos;                                         /* :787 */
+                    v3 focalPoint = add(camPos, muls(rayDir0, cam->focal_dist));   /* :788 */
+                    float r1 = rnd(&rng), r2 = rnd(&rng), off[2];
+                    orc_sample_circle(r1, r2, off);
+                    off[0] = off[0] * cam->aperture; off[1] = off[1] * cam->aperture;   /* :789 */
+                    camPos = add(camPos, add(muls(f.right, off[0]), muls(f.up, off[1])));   /* :790 */
+                    v3 rayDir = normalize(sub(focalPoint, camPos));            /* :791 */
+                    v3 color = trace(s, camPos, rayDir, D, &rng);              /* :793 */
+                    acc = add(acc, color);                                     /* :798-800 */
+                }
+                total[px] = acc.x; total[px + 1] = acc.y; total[px + 2] = acc.z;
+                if (rgb8)
+                {
+                    float ns = (float)(first_sample + spp);                    /* (float)mSamples */
+                    float c[3] = { acc.x / ns, acc.y / ns, acc.z / ns };
+                    for (int k = 0; k < 3; k++)
+                    {
+                        float x = c[k];
+                        x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);           /* glm::clamp; NaN -> NaN */
+                        if (!(x == x)) x = 0.0f;
+                        rgb8[px + k] = (uint8_t)(x * 255);                     /* :810-812 truncation */
+                    }
                 }
             }
         }
-        free(dirs);
     }
+    free(dirs_all);
 }

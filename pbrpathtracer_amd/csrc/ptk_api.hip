@@ -451,7 +451,7 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
             c->acc_pending[b] = true;
             c->pass_counter++;
         }
-        c->last_passes++; c->last_launches += 2;
+        c->last_passes++; c->last_launches += 3;            // queue_init_kernel (queue + parameter block), trace, accumulate
         done += n;
     }
     return PTK_OK;

@@ -92,8 +92,10 @@ def test_bench_exchange_on_one_gpu():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["config"]["exchange_every"] == 2 and d["config"]["exchanges_in_timed_region"] == 3      # steps 2, 4 and the last
     assert "native packed RCCL gather" in d["config"]["exchange"]
-    assert d["roofline"]["bound"] in ("valu", "hbm") and 0 < d["roofline"]["frac"] < 1
+    assert d["roofline"]["bound"] in ("valu", "l2_miss_fabric") and 0 < d["roofline"]["frac"] < 1
     assert 0 < d["traced_samples_per_s"] <= d["value"]
+    assert d["config"]["rccl_ranks"] == 1 and d["config"]["devices"] == [0]      # ncclCommCount of the library's own communicator
+    assert d["parity"]["ok"] is True and d["parity"]["exact_fraction"] == 1.0
 
 
 def test_bench_two_ranks_rehearsal_self_launched():
@@ -103,15 +105,26 @@ def test_bench_two_ranks_rehearsal_self_launched():
     gathered image must hold exactly what the two ranks hold together."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--config", "C1", "--backend", "gloo", "--exchange-every", "2", "--no-cpu-baseline"],
+                        "--config", "C1", "--backend", "gloo", "--exchange-every", "2", "--no-cpu-baseline", "--with-c5"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert "gathered-image checksum OK" in r.stderr, r.stderr[-3000:]
+    assert "C1 gathered-image checksum OK" in r.stderr and "C5 gathered-image checksum OK" in r.stderr, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines                                            # ONE line: rank 0's result
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["parallelism"] == "tile-split x2" and d["config"]["exchanges_in_timed_region"] == 2
+    # the self-proving fields: what the library's own communicator reports (none in the gloo rehearsal), the distinct HIP
+    # ordinals the ranks rendered on (both ranks share this box's one GPU), the exchange's checksum
+    assert "rccl_ranks" in d["config"] and d["config"]["rccl_ranks"] is None and d["config"]["devices"] == [0]
+    assert d["config"]["gathered_checksum"]["ok"] is True
+    # image parity beside the number, and the contracted build next to the exact one
+    assert d["parity"]["ok"] is True and d["parity"]["exact_fraction"] == 1.0 and d["parity"]["pixels"] > 0
+    assert d["value_contracted"]["value"] > 0 and d["value_contracted"]["parity"]["ok"] is True
+    # BASELINE config 5 as stated - the 1 M-triangle frame tile-split over the ranks with the exchange in the timed region
+    c5 = d["other_configs"]["C5"]
+    assert c5["n_gpus"] == 2 and c5["value"] > 0 and c5["triangles"] >= 1000000 and c5["config"]["gathered_checksum"]["ok"] is True
+    assert c5["config"]["exchanges_in_timed_region"] == 1 and c5["parity"]["ok"] is True
 
 
 def test_native_gather_between_two_gpus(tmp_path):

@@ -1,0 +1,208 @@
+"""Turn the raw output of tools/profile_r03.sh (gpurun_out/<dir>) into the tracked summaries under profiles/<dir>.
+
+    python tools/profile_collect_r03.py gpurun_out/r03x profiles/r03
+
+Writes (whatever the raw directory holds):
+  bench_C{1..5}.json                          the bench lines
+  rocprofv3_kernel_stats_C{2,4}.csv           per-kernel time of `bench.py --opts overlap=0` (launches not overlapped)
+  traffic_C{2..5}.json (+ ../traffic_Cn.json) HBM bytes per trace_kernel launch: FETCH_SIZE x2 (gfx950: 128-B requests tallied
+                                              at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, and the L2 hit rate TCC_HIT / (HIT + MISS)
+  pmc_sq_trace_kernel_C{2,4,5}.json           SQ counters of the full-size launches + the instruction-class counters + the issue
+                                              cycles they imply with the measured per-class costs (valu_calibration.json)
+  pmc_mem_trace_kernel_C{4,5}.json            TA / TCP / TD counters: how busy the vector-memory (gather) path is
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import hashlib
+
+
+def kernel_source_sha256():
+    """the counter files are tied to the kernel sources they were collected for (bench.py ignores them once these change)"""
+    f = os.path.join(src, "kernel_source_sha256.txt")          # written on the GPU box by profile_r03.sh from the sources that ran
+    if os.path.exists(f):
+        return open(f).read().strip()
+    h = hashlib.sha256()
+    for n in ("ptk_kernels.hip", "ptk_device.h"):
+        h.update(open(os.path.join(ROOT, "pbrpathtracer_amd", "csrc", n), "rb").read())
+    return h.hexdigest()
+
+
+SHA = kernel_source_sha256()
+TRACE = "trace_kernel<false"
+
+
+def dispatches(d, kernel_substr):
+    """one dict per dispatch of the kernels whose name contains kernel_substr: {counter: value, ms, grid, kernel}"""
+    per = collections.defaultdict(dict)
+    for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Kernel_Name"]:
+                e = per[(f, r["Dispatch_Id"])]
+                e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                e["ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+                e["grid"] = int(r["Grid_Size"]); e["kernel"] = r["Kernel_Name"]; e["vgpr"] = r.get("VGPR_Count")
+    return list(per.values())
+
+
+def full_launches(ds):
+    """the full-size launches = the long ones (not the 1-spp set-up launch or the short counters-enabled run); the grid
+    size does not tell them apart: big launches run as a fixed number of persistent waves"""
+    if not ds:
+        return []
+    longest = max(x["ms"] for x in ds)
+    return [x for x in ds if x["ms"] >= 0.5 * longest]
+
+
+def mean_of(ds, key):
+    v = [x[key] for x in ds if key in x]
+    return sum(v) / len(v) if v else None
+
+
+bench = {}
+for c in ("C1", "C2", "C3", "C4", "C5"):
+    f = os.path.join(src, f"bench_{c}.json")
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, f"bench_{c}.json"))
+        try:
+            bench[c] = json.load(open(f))
+        except Exception:
+            pass
+for c in ("C2", "C4"):
+    for f in glob.glob(f"{src}/ktrace_{c}/**/*_kernel_stats.csv", recursive=True):
+        shutil.copy(f, os.path.join(dst, f"rocprofv3_kernel_stats_{c}.csv"))
+
+# the DEFAULT (overlap = 1) C2 run: start / end of consecutive trace_kernel launches - how much of a launch's tail the next
+# launch covers, i.e. why ms_per_step < the isolated kernel time
+rows = []
+for f in glob.glob(f"{src}/ktrace_overlap_C2/**/*_kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if TRACE in r["Kernel_Name"]:
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+rows.sort()
+if len(rows) > 8:
+    durs = [(e - s) / 1e6 for s, e in rows]
+    longest = max(durs)
+    full = [(s, e) for (s, e), d in zip(rows, durs) if d >= 0.5 * longest]
+    pairs = []
+    for (s0, e0), (s1, e1) in zip(full[:-1], full[1:]):
+        pairs.append({"launch_ms": round((e0 - s0) / 1e6, 4), "next_start_after_this_start_ms": round((s1 - s0) / 1e6, 4),
+                      "overlap_ms": round(max(0, e0 - s1) / 1e6, 4)})
+    steady = pairs[len(pairs) // 4:]
+    ov = {"command": "rocprofv3 --kernel-trace -- python3 bench.py --config C2 --steps 40 --warmup 5 --no-cpu-baseline --no-other-configs --no-parity --no-contracted --no-interactive   (overlap option at its default, 1)",
+          "kernel": "trace_kernel<false, true>", "full_launches": len(full),
+          "mean_launch_ms": round(sum(p["launch_ms"] for p in steady) / len(steady), 4),
+          "mean_start_to_start_ms": round(sum(p["next_start_after_this_start_ms"] for p in steady) / len(steady), 4),
+          "mean_overlap_ms": round(sum(p["overlap_ms"] for p in steady) / len(steady), 4),
+          "note": "consecutive launches alternate between two streams; launch k+1 starts while launch k's last waves (its longest paths) are still running: "
+                  "start-to-start (= ms_per_step) is shorter than a launch by the mean overlap", "kernel_source_sha256": SHA, "pairs_head": pairs[:12]}
+    json.dump(ov, open(os.path.join(dst, "overlap_trace_C2.json"), "w"), indent=1)
+    print("overlap C2:", {k: v for k, v in ov.items() if k.startswith("mean") or k == "full_launches"})
+for name in ("valu_calibration.json", "gather_ceiling.json", "exact_math.json"):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, name))
+
+SPP = {"C1": 16, "C2": 256, "C3": 512, "C4": 256, "C5": 1024}
+for c in ("C2", "C3", "C4", "C5"):
+    base = os.path.join(src, f"traffic_{c}")
+    if not os.path.isdir(base):
+        continue
+    ds = {n: full_launches(dispatches(os.path.join(base, p), TRACE)) for n, p in (("fetch", "p1"), ("write", "p2"), ("tcc", "p3"))}
+    if not ds["fetch"] or not ds["write"]:
+        continue
+    fetch, write = mean_of(ds["fetch"], "FETCH_SIZE"), mean_of(ds["write"], "WRITE_SIZE")
+    hit, miss = mean_of(ds["tcc"], "TCC_HIT_sum"), mean_of(ds["tcc"], "TCC_MISS_sum")
+    acc = {n: full_launches(dispatches(os.path.join(base, p), "accumulate_kernel")) for n, p in (("fetch", "p1"), ("write", "p2"))}
+    out = {
+        "config": c, "spp": SPP[c], "n_gpus": 1, "kernel": ds["fetch"][0]["kernel"], "kernel_source_sha256": SHA,
+        "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
+        "fetch_size_kib": fetch, "write_size_kib": write,
+        "launches_averaged": len(ds["fetch"]), "kernel_ms_under_profiler": mean_of(ds["fetch"], "ms"),
+        "hbm_GBps": (2 * fetch + write) * 1024 / (mean_of(ds["fetch"], "ms") * 1e-3) / 1e9,
+        "cache": None if hit is None else {"TCC_HIT": hit, "TCC_MISS": miss, "l2_hit_rate": hit / max(1.0, hit + miss),
+                                            "TCC_REQ": mean_of(ds["tcc"], "TCC_REQ_sum"), "TCC_READ": mean_of(ds["tcc"], "TCC_READ_sum"),
+                                            "note": "L2 (TCC) requests of one launch, summed over the 8 XCDs; what misses goes to the Infinity Cache / HBM (FETCH_SIZE)"},
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum (three separate passes) on "
+                  "`python3 bench.py --config %s --no-cpu-baseline --no-other-configs --opts overlap=0`; FETCH_SIZE x2 per MI355X_MICROARCH.md "
+                  "(gfx950 counts 128-B requests as 64 B), WRITE_SIZE as read" % c,
+        "accumulate_kernel": {"FETCH_SIZE_KiB": mean_of(acc["fetch"], "FETCH_SIZE"), "WRITE_SIZE_KiB": mean_of(acc["write"], "WRITE_SIZE"),
+                              "ms": mean_of(acc["fetch"], "ms")},
+    }
+    json.dump(out, open(os.path.join(dst, f"traffic_{c}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(os.path.dirname(dst.rstrip("/")), f"traffic_{c}.json"), "w"), indent=1)
+    print(c, "traffic %.3f GB per launch, %.1f GB/s, L2 hit %.3f" % (out["hbm_bytes_per_launch"] / 1e9, out["hbm_GBps"],
+                                                                   out["cache"]["l2_hit_rate"] if out["cache"] else -1))
+
+# measured issue cost per instruction class (cycles a SIMD spends per wave-instruction, 4 waves per SIMD)
+cal = {}
+cf = os.path.join(dst, "valu_calibration.json")
+if not os.path.exists(cf):
+    cf = os.path.join(ROOT, "profiles", "r02", "valu_calibration.json")      # the calibration microbenchmark of round 2 (hardware, not kernels)
+if os.path.exists(cf):
+    for r in json.load(open(cf))["rows"]:
+        cal[r["op"]] = r["w4"]["cyc"]
+
+
+def merge(base, passes, kern=TRACE):
+    m = {}
+    for p in sorted(glob.glob(os.path.join(base, passes))):
+        ds = full_launches(dispatches(p, kern))
+        for k in (ds[0] if ds else {}):
+            if k not in ("grid", "kernel", "vgpr"):
+                m[k] = sum(x[k] for x in ds) / len(ds)
+        if ds:
+            m["kernel"] = ds[0]["kernel"]; m["grid_threads"] = ds[0]["grid"]; m["vgpr"] = ds[0]["vgpr"]
+    return m
+
+
+for c in ("C2", "C4", "C5"):
+    m = merge(os.path.join(src, f"sq_{c}"), "p*")
+    if "SQ_INSTS_VALU" not in m:
+        continue
+    cl = merge(os.path.join(src, f"class_{c}"), "p*")
+    m["lane_utilisation"] = m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_INSTS_VALU"])
+    m["wave_life_in_s_waitcnt"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
+    m["wave_life_waiting_to_issue"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
+    # SQ_BUSY_CYCLES counts per shader engine (32 of them) in cycles: its mean over the launch gives the clock the chip held
+    m["clock_GHz_from_SQ_BUSY_CYCLES"] = m["SQ_BUSY_CYCLES"] / 32.0 / (m["ms"] * 1e-3) / 1e9
+    clock = m["clock_GHz_from_SQ_BUSY_CYCLES"] if 1.0 < m["clock_GHz_from_SQ_BUSY_CYCLES"] < 2.6 else 2.1
+    simd_cycles = 1024 * clock * 1e9 * m["ms"] * 1e-3                 # issue cycles available: 256 CUs x 4 SIMDs
+    m["avg_waves_per_simd"] = m["SQ_WAVE_CYCLES"] * 4 / simd_cycles
+    # calibrated issue cycles: SQ_ACTIVE_INST_VALU charges one quad-cycle to every non-transcendental instruction, whatever it
+    # costs the pipe (profiles/r02/valu_calibration.json: v_fma/v_mul/v_add/v_mov/logic ~2.4 cycles, v_cmp/v_cndmask/v_min/v_max/
+    # cvt/v_mul_lo/packed f32/f64 ~4.3, transcendental ~8.2), so the pipe's occupancy is bounded from the class counters instead
+    if cl and cal:
+        full = sum(cl.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"))
+        trans = cl.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+        rest = max(0.0, m["SQ_INSTS_VALU"] - full - trans)
+        lo = full * cal["fma"] + trans * cal["rcp"] + rest * cal["xor"]           # everything else at the full rate
+        hi = full * cal["pk_mul"] + trans * cal["rcp"] + rest * cal["cmp"]        # packed forms of add/mul, everything else half rate
+        m["classes"] = {k: v for k, v in cl.items() if k.startswith("SQ_INSTS")}
+        m["valu_issue_cycles_used_low"] = lo; m["valu_issue_cycles_used_high"] = hi
+        m["valu_pipe_busy_low"] = lo / simd_cycles; m["valu_pipe_busy_high"] = hi / simd_cycles
+        m["valu_pipe_busy_note"] = ("issue cycles used / available (1024 SIMDs x clock x kernel time).  low: add/mul/fma f32 counted at the "
+                                    "scalar full-rate cost and every other non-transcendental instruction at the full rate too; high: add/mul "
+                                    "counted as packed (v_pk_*, half rate per instruction) and every other instruction (compares, selects, "
+                                    "min/max, conversions, integer multiplies, f64) at the measured half rate.  The truth lies between; the "
+                                    "kernels' compares / selects / conversions put it near the high figure.")
+    m["kernel_source_sha256"] = SHA
+    m["units"] = "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are in quad-cycles summed over waves; ms is the kernel time under the profiler"
+    json.dump(m, open(os.path.join(dst, f"pmc_sq_trace_kernel_{c}.json"), "w"), indent=1)
+    print(c, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in m.items() if k[0].islower() and k not in ("classes", "valu_pipe_busy_note", "units", "kernel")})
+
+for c in ("C4", "C5"):
+    m = merge(os.path.join(src, f"mem_{c}"), "p*")
+    if not m:
+        continue
+    json.dump(m, open(os.path.join(dst, f"pmc_mem_trace_kernel_{c}.json"), "w"), indent=1)
+    print(c, "mem", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in m.items() if k not in ("kernel",)})
