@@ -475,6 +475,11 @@ __global__ __launch_bounds__(kThreads) void collapse_kernel(const BNode* __restr
     // padded child boxes (the host pads every triangle box by `pad` before building; min / max commute with that)
     float cmn[4][3], cmx[4][3], umn[3] = { INFINITY, INFINITY, INFINITY }, umx[3] = { -INFINITY, -INFINITY, -INFINITY };
     int32_t link[4];
+    // the interior children of one node get CONSECUTIVE numbers (one counter bump per node, not per child): a ray that enters
+    // two of them finds the second record in the 128-byte line the first brought in (or in its neighbour)
+    int n_interior = 0;
+    for (int k = 0; k < nc; k++) if (nodes[child[k]].left >= 0) n_interior++;
+    int pos = n_interior > 0 ? (int)atomicAdd(&counters[CNT_QUEUE], (uint32_t)n_interior) : 0;
     for (int k = 0; k < 4; k++)
     {
         link[k] = NODE_EXIT;
@@ -488,10 +493,10 @@ __global__ __launch_bounds__(kThreads) void collapse_kernel(const BNode* __restr
         if (c.left < 0) link[k] = ~((c.first << 3) | (c.count - 1));
         else
         {
-            const int pos = (int)atomicAdd(&counters[CNT_QUEUE], 1u);
             WideItem w; w.bnode = child[k]; w.budget = it.budget - (nc - 1); w.used = it.used + (nc - 1); w.pad = 0;
             next_queue[pos] = w;
             link[k] = next_start + pos;
+            pos++;
         }
     }
     float scale[3];

@@ -35,6 +35,7 @@ struct ptk_ctx {
     int4* d_texinfo = nullptr;
     uint32_t* d_texels = nullptr;
     int num_nodes = 0, num_tris = 0, num_lights = 0, bvh_depth = 0, bvh_stack = 0, num_leaf_tris = 0;
+    float scene_bound = 0.0f;           // 3.1 x (1.01 x the largest |vertex coordinate| + 1e-3): RenderParams::scene_bound
     bool have_scene = false;
     double upload_ms[4] = { 0, 0, 0, 0 };       // last ptk_upload_scene: BVH build, record packing, device copies, total
     // host copies kept for ptk_update_materials: what was uploaded, the texture index map, the light records
@@ -263,7 +264,7 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     p.generations = c->opt_generations > 0 ? c->opt_generations : (c->world > 1 ? 2 : 1);
     p.rgb8_host = nullptr; p.rgb8_host_full = 1;
     p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.exit_gen = c->render_gen.load(); p.stats = c->d_stats;
-    p.num_nodes = c->num_nodes; p.num_lights = c->num_lights;
+    p.num_nodes = c->num_nodes; p.num_lights = c->num_lights; p.scene_bound = c->scene_bound;
     p.flat_count = (c->opt_flat && c->num_tris <= 16 && c->d_flat_tris) ? c->num_tris : 0;
     p.flat_shade_w = c->opt_flat_shade_w; p.flat_gen_w = c->opt_flat_gen_w;
     p.width = c->width; p.height = c->height; p.max_depth = c->max_depth;
@@ -580,8 +581,14 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
         if (s->lights[i] < 0 || s->lights[i] >= n) return fail(c, PTK_ERR_BAD_ARG, "light triangle index out of range");
     // the kernels' exact short reciprocal (ptk_kernels.hip rcp_ieee) covers determinants and lengths up to 2^126: coordinates
     // must stay below 2^61 in magnitude (the reference's own float arithmetic is long meaningless out there)
+    float vmax = 0.0f;
     for (size_t i = 0; i < (size_t)n * 9; i++)
+    {
         if (!(std::fabs(s->verts[i]) < 2.305843e18f)) return fail(c, PTK_ERR_LIMIT, "vertex coordinate is not finite or exceeds 2^61");
+        vmax = std::max(vmax, std::fabs(s->verts[i]));
+    }
+    // (node origins lie within the triangle boxes padded by 1e-5 x their extent plus the degenerate-box epsilon)
+    const float scene_bound = 3.1f * (1.01f * vmax + 1e-3f);
     for (int32_t i = 0; i < s->num_textures; i++)
     {
         const ptk_texture& t = s->textures[i];
@@ -760,6 +767,7 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     HIPCHK(c, up((void**)&c->d_texinfo, texinfo.data(), texinfo.size() * sizeof(int4)));
     HIPCHK(c, up((void**)&c->d_texels, texels.data(), texels.size() * 4));
     c->num_nodes = bvh.num_nodes; c->num_tris = n; c->num_lights = s->num_lights; c->bvh_depth = bvh.depth; c->bvh_stack = bvh.stack_need;
+    c->scene_bound = scene_bound;
     c->scene_has_opacity = false;
     for (int32_t i = 0; i < n; i++)
         if (s->materials[s->material[i]].tex[5] >= 0) { c->scene_has_opacity = true; break; }
@@ -1488,7 +1496,7 @@ int ptk_probe_hits(ptk_ctx* c, int n, const float* ro, const float* rd, int32_t*
         ProbeParams p = {};
         p.nodes = c->d_nodes; p.tris = c->d_tris; p.shade = c->d_shade; p.mats = c->d_mats;
         p.texinfo = c->d_texinfo; p.texels = c->d_texels; p.ro = d_ro; p.rd = d_rd; p.tri = d_tri; p.tuv = d_tuv;
-        p.n = n; p.num_nodes = c->num_nodes;
+        p.n = n; p.num_nodes = c->num_nodes; p.scene_bound = c->scene_bound;
         launch_probe(p, c->stream);
         e = hipGetLastError();
     }
@@ -1517,7 +1525,7 @@ int ptk_probe_direct(ptk_ctx* c, int n, const float* pts, const float* normals, 
         ProbeParams p = {};
         p.nodes = c->d_nodes; p.tris = c->d_tris; p.shade = c->d_shade; p.mats = c->d_mats;
         p.texinfo = c->d_texinfo; p.texels = c->d_texels; p.lights = c->d_lights; p.num_lights = c->num_lights;
-        p.n = n; p.num_nodes = c->num_nodes;
+        p.n = n; p.num_nodes = c->num_nodes; p.scene_bound = c->scene_bound;
         launch_probe_direct(p, d[0], d[1], d[2], d[3], d[4], c->stream);
         e = hipGetLastError();
     }

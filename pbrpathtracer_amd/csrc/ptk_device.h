@@ -89,6 +89,7 @@ struct RenderParams {
     uint32_t exit_gen;          // this render's generation: its kernels stand down when *exit_flag >= exit_gen (Exit() cuts everything in flight)
     unsigned long long* stats;  // 7 counters (STATS variant only)
     int num_nodes, num_lights;
+    float scene_bound;          // 3.1 x the largest |coordinate| of the scene's padded bounds: the per-ray slack of the slab tests (Walk::begin)
     int flat_shade_w, flat_gen_w; // FLAT block-choice weights (eighths) of the shade / camera-ray blocks vs the triangle pass
     int flat_count;             // > 0: tiny scene, test all flat_count triangle records per ray without a BVH walk
     int width, height, max_depth;
@@ -121,6 +122,7 @@ struct ProbeParams {
     int32_t* tri;
     float* tuv;
     int n, num_nodes;
+    float scene_bound;
     const float4* lights;       // probe_direct only
     int num_lights;
 };

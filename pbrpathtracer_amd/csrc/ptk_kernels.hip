@@ -265,6 +265,7 @@ struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex, walk_iters, w
 // stack[k * PTK_BLOCK].
 struct Walk {
     v3 ro, rd, inv;
+    v3 slack;                    // per axis: what the slab distances of any node of the scene can be off by for this ray (walk_step)
     int node;
     int* top;                    // this lane's stack top in LDS (== its column's base when empty); unused by the FLAT kernel
     int tri_next, tri_left;      // pending leaf: records [tri_next, tri_next + tri_left) still to test
@@ -280,7 +281,7 @@ struct Walk {
 
     // node: >= 0 interior node to test next; NODE_EXIT nothing left on the node side; any other negative
     // value = a leaf waiting for the triangle queue (tri_next, tri_left) to drain
-    __device__ __forceinline__ void begin(v3 o, v3 d, int num_nodes, int* stack)
+    __device__ __forceinline__ void begin(v3 o, v3 d, int num_nodes, int* stack, float scene_bound)
     {
         ro = o; rd = d;
         // acceleration only: 1-ulp reciprocals are fine for conservative slab tests.  Clamped to +-1e18 so that a ray
@@ -290,6 +291,15 @@ struct Walk {
         // 228 153 node visits for one ray of the 1 M-triangle scene, a 0.5 s tail per launch)
         inv = V(__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e18f, 1e18f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e18f, 1e18f),
                 __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e18f, 1e18f));
+#if PTK_ROBUST_BOXES
+        // The slab arithmetic of walk_step, t = fma(q, A, B) with A = scale * inv and B = (origin - ro) * inv, is off by at most
+        // 2^-21 (|B| + 256 |A|) (see there).  Every node origin lies inside the scene's padded bounds and a node's 255 grid
+        // steps span at most the scene, so per axis that is at most 2^-21 (|ro| + 3.1 scene_bound) |inv| - a property of the RAY,
+        // computed here once instead of twelve instructions per node visited.  (In position units 5e-7 x the scene's size:
+        // nothing next to a node's own extent until rays come from ~10^5 scene sizes away, where it is exactly what is needed.)
+        slack = V((fabsf(o.x) + scene_bound) * fabsf(inv.x) * 0x1p-21f, (fabsf(o.y) + scene_bound) * fabsf(inv.y) * 0x1p-21f,
+                  (fabsf(o.z) + scene_bound) * fabsf(inv.z) * 0x1p-21f);
+#endif
         node = num_nodes > 0 ? 0 : NODE_EXIT;
         top = stack;
         tri_next = 0; tri_left = 0;
@@ -463,9 +473,9 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
         // exceeds an 8-bit grid step once that distance is > 65 000 node extents (and Moeller-Trumbore's own decisions carry
         // the same uncertainty, so no padding of the tree can stand in for it).  Near planes are taken that much (x 2) too
         // early and far planes too late; found by tools/soak_bvh.py: two clusters of 1e-3 at +-1e3 gave tree-dependent hits.
-        const float sx = __builtin_fmaf(fabsf(Ax), 0x1p-13f, fabsf(Bx) * 0x1p-21f), sy = __builtin_fmaf(fabsf(Ay), 0x1p-13f, fabsf(By) * 0x1p-21f),
-                    sz = __builtin_fmaf(fabsf(Az), 0x1p-13f, fabsf(Bz) * 0x1p-21f);
-        const float Bnx = Bx - sx, Bny = By - sy, Bnz = Bz - sz, Bfx = Bx + sx, Bfy = By + sy, Bfz = Bz + sz;
+        // The bound is taken per RAY (Walk::begin: |B| <= (|ro| + scene bound) |inv|, 256 |A| <= 2.01 scene bound |inv|), not
+        // per node: six additions here instead of twelve instructions.
+        const float Bnx = Bx - W.slack.x, Bny = By - W.slack.y, Bnz = Bz - W.slack.z, Bfx = Bx + W.slack.x, Bfy = By + W.slack.y, Bfz = Bz + W.slack.z;
 #else
         const float Bnx = Bx, Bny = By, Bnz = Bz, Bfx = Bx, Bfy = By, Bfz = Bz;
 #endif
@@ -763,7 +773,7 @@ __device__ __forceinline__ bool shade_interaction(const PT& P, Walk& W, Walk& WS
                     {
                         // the shadow ray rides along with the bounce ray in the next flat pass, which finds its
                         // closest hit over ALL triangles (no early end: the pass runs for the bounce ray anyway)
-                        WS.begin(p, l, P.num_nodes, stack);
+                        WS.begin(p, l, P.num_nodes, stack, P.scene_bound);
                         WS.occl_tri = light_tri;
                     }
                     else
@@ -775,7 +785,7 @@ __device__ __forceinline__ bool shade_interaction(const PT& P, Walk& W, Walk& WS
                 }
             }
             T = mulv(T, weight);
-            W.begin(next_ro, next_rd, P.num_nodes, stack);
+            W.begin(next_ro, next_rd, P.num_nodes, stack, P.scene_bound);
             // a shadow ray meets its light triangle before anything else (see Walk::occl_tri)
             if (!FLAT && W.occl_tri >= 0) (void)tri_test<STATS>(P, W, lt0, lt1, lt2, rng, ray, cnt);
         }
@@ -956,10 +966,10 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
 
     // per-lane path state
     Walk W;
-    W.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0, stack);
+    W.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0, stack, 0.0f);
     W.occl_tri = -1;
     Walk WS;                        // FLAT only: the shadow ray, tested in the same pass as the bounce ray
-    WS.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0, stack);
+    WS.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0, stack, 0.0f);
     WS.occl_tri = -1;
     v3 L = V(0.0f, 0.0f, 0.0f), T = V(1.0f, 1.0f, 1.0f);
     v3 Tdi = V(0.0f, 0.0f, 0.0f), nextDir = V(0.0f, 0.0f, 1.0f);
@@ -988,7 +998,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
             if (STATS) cnt.shadow++;                                                              \
             if (!(hit_ && W.best.tri != W.occl_tri)) L = add(L, Tdi);                             \
             W.occl_tri = -1;                                                                      \
-            W.begin(W.ro, nextDir, P.num_nodes, stack);                                                  \
+            W.begin(W.ro, nextDir, P.num_nodes, stack, P.scene_bound);                                                  \
         }                                                                                         \
         else if (!hit_) PTK_FINISH_PATH();              /* :550 miss -> black */                  \
         else st = ST_SHADE;                                                                       \
@@ -1217,7 +1227,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                         ro = add(camPos0, add(muls(camRight, offx), muls(camUp, offy)));
                     }
                     v3 rd = normalize(sub(focalPoint, ro));
-                    W.begin(ro, rd, P.num_nodes, stack);
+                    W.begin(ro, rd, P.num_nodes, stack, P.scene_bound);
                     st = ST_TRAV;
                     if (!PTK_FUSED_START && P.primary_hit)
                     {
@@ -1485,7 +1495,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES_BVH) void trace_po
         // ---- TRACE phase: the suspended walks resume, the list's jobs are dealt to whichever lane is free -------------------
         {
             Walk W;
-            W.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0, stack);
+            W.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0, stack, 0.0f);
             W.occl_tri = -1;
             Rng rng; rng.inc = 1u; rng.state = 0u; rng.key = 0u;      // (the walk only needs the key: stochastic opacity)
             v3 nextDir = V(0.0f, 0.0f, 1.0f);
@@ -1502,7 +1512,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES_BVH) void trace_po
                 const float4 J0 = rec[0], J1 = rec[1], J2 = rec[2];
                 const bool in_bounce = (fl >> 17) & 1u, had_shadow = __float_as_int(J0.w) >= 0;
                 // (the second ray of a job with a shadow ray goes along d2; any other ray along d1)
-                W.begin(V(J0.x, J0.y, J0.z), (in_bounce && had_shadow) ? V(J2.x, J2.y, J2.z) : V(J1.x, J1.y, J1.z), P.num_nodes, stack);
+                W.begin(V(J0.x, J0.y, J0.z), (in_bounce && had_shadow) ? V(J2.x, J2.y, J2.z) : V(J1.x, J1.y, J1.z), P.num_nodes, stack, P.scene_bound);
                 W.occl_tri = in_bounce ? -1 : __float_as_int(J0.w);
                 rng.key = __float_as_uint(J1.w);
                 nextDir = V(J2.x, J2.y, J2.z);
@@ -1524,7 +1534,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES_BVH) void trace_po
                 bool fin = false;               // this lane finished a job in this iteration
                 if (jst == J_LOAD)
                 {
-                    W.begin(V(tj0.x, tj0.y, tj0.z), V(tj1.x, tj1.y, tj1.z), P.num_nodes, stack);
+                    W.begin(V(tj0.x, tj0.y, tj0.z), V(tj1.x, tj1.y, tj1.z), P.num_nodes, stack, P.scene_bound);
                     W.occl_tri = __float_as_int(tj0.w);
                     rng.key = __float_as_uint(tj1.w);
                     nextDir = V(tj2.x, tj2.y, tj2.z);
@@ -1593,7 +1603,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES_BVH) void trace_po
                                 if (STATS) cnt.shadow++;
                                 lit = !(hit_ && W.best.tri != W.occl_tri);
                                 W.occl_tri = -1;
-                                W.begin(W.ro, nextDir, P.num_nodes, stack);
+                                W.begin(W.ro, nextDir, P.num_nodes, stack, P.scene_bound);
                             }
                             else
                             {
@@ -1769,7 +1779,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void primary_hits_kernel(const RenderPar
     v3 rd = normalize(sub(focalPoint, camPos0));
     Walk W;
     W.occl_tri = -1;
-    W.begin(camPos0, rd, P.num_nodes, lds_stack + threadIdx.x);
+    W.begin(camPos0, rd, P.num_nodes, lds_stack + threadIdx.x, P.scene_bound);
     while (!W.done()) walk_step<false, PTK_BLOCK>(P, W, rng, 0u, lds_stack + threadIdx.x, cnt);
     out[i] = make_float4(__int_as_float(W.best.tri), W.best.t, W.best.u, W.best.v);
     out_rd[i] = make_float4(rd.x, rd.y, rd.z, 0.0f);           // the very floats the camera-ray block computes for a zero lens offset
@@ -1787,7 +1797,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_hits_kernel(const ProbeParams
     v3 rd = V(P.rd[i * 3], P.rd[i * 3 + 1], P.rd[i * 3 + 2]);
     Walk W;
     W.occl_tri = -1;
-    W.begin(ro, rd, P.num_nodes, lds_stack + threadIdx.x);
+    W.begin(ro, rd, P.num_nodes, lds_stack + threadIdx.x, P.scene_bound);
     while (!W.done()) walk_step<false, PTK_BLOCK>(P, W, rng, 0u, lds_stack + threadIdx.x, cnt);
     bool hit = W.best.tri != PTK_NOHIT;
     P.tri[i] = hit ? W.best.tri : -1;
@@ -1812,7 +1822,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void probe_direct_kernel(const ProbePara
     if (P.num_lights > 0 && sample_direct_light(P, p, n, diffuse, tape[i * 3], tape[i * 3 + 1], tape[i * 3 + 2], l, di, light_tri, lt0, lt1, lt2))
     {
         Walk W;
-        W.begin(p, l, P.num_nodes, lds_stack + threadIdx.x);
+        W.begin(p, l, P.num_nodes, lds_stack + threadIdx.x, P.scene_bound);
         W.occl_tri = light_tri;
         (void)tri_test<false>(P, W, lt0, lt1, lt2, rng, 0u, cnt);
         while (!W.done()) walk_step<false, PTK_BLOCK>(P, W, rng, 0u, lds_stack + threadIdx.x, cnt);
