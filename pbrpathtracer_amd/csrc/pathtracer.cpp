@@ -279,6 +279,7 @@ struct PathTracer::Impl {
     glm::ivec2 resolution = glm::ivec2(0, 0);
     GLubyte* out_img = 0;
     GLubyte* bound_img = 0;             // what ptk_bind_out_image holds (bound lazily: binding needs the frame)
+    bool bind_dirty = true;             // the library may have dropped the binding: call ptk_bind_out_image again, whatever the pointer
     int max_depth = 3;                                     // pathtracer.cpp:15
 
     float cam_pos[3] = { 0, 0, 0 }, cam_dir[3] = { 0, 0, 1 }, cam_up[3] = { 0, 1, 0 };   // :17-18
@@ -531,10 +532,11 @@ void PathTracer::RenderFrames(int count)
         m->note(rc);
         if (rc != PTK_OK) return;
         m->frame_dirty = false;
-        m->bound_img = 0;                                               // (a new resolution unbinds the hand-off buffer)
+        m->bind_dirty = true;                                           // (a new resolution unbinds the hand-off buffer: say again what is bound)
     }
-    if (m->out_img != m->bound_img)
+    if (m->bind_dirty || m->out_img != m->bound_img)
     {
+        m->bind_dirty = false;
         // SetOutImage (:297-300): the 8-bit resolve goes straight into the caller's buffer from now on
         m->note(ptk_bind_out_image(m->ctx, m->out_img));
         m->bound_img = m->out_img;

@@ -305,6 +305,12 @@ def test_bound_handoff_buffer_tracks_every_frame(tmp_path, oracle_mod):
         pt.SetOutImage(None)
         pt.RenderFrame()                                                               # unbound again: nothing may touch out2
         assert np.array_equal(out2, dev2)
+        # ... nor when the unbinding coincides with a frame change and a reset (found by tools/soak_api.py: the binding was
+        # then kept, and ResetImage cleared a buffer the caller had already freed)
+        pt.SetOutImage(out2); pt.RenderFrame()
+        out2[:] = 201
+        pt.SetOutImage(None); pt.SetTraceDepth(3); pt.ResetImage(); pt.RenderFrame(); pt.RenderFrame()
+        assert (out2 == 201).all()
         pt.close()
         del out, out2
 

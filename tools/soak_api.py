@@ -28,8 +28,13 @@ for k in range(count):
     other = PathTracer(0); other.LoadSceneFile(built["C1"][0])
     cam = camera_from_scene(scene)
     st = dict(W=pt.GetResolution()[0], H=pt.GetResolution()[1], D=pt.GetTraceDepth(), seed=0)
+    out_img = None
     for stage in range(int(rng.integers(3, 8))):
         op = int(rng.integers(0, 8))
+        # the hand-off buffer comes and goes, pageable (page-locked in place) or from AllocOutImage
+        if rng.uniform() < 0.5:
+            kind = int(rng.integers(0, 3))
+            out_img = None if kind == 0 else "pending-%d" % kind
         if op == 0:
             cam["pos"] = (np.asarray(cam["pos"], np.float32) + rng.uniform(-0.3, 0.3, 3).astype(np.float32)); pt.SetCamera(cam["pos"], cam["dir"], cam["up"])
         elif op == 1:
@@ -50,6 +55,12 @@ for k in range(count):
             pt.SetMaterial(ob, int(rng.integers(0, max(1, objs[ob]))), m)
         else:
             cam["focal_dist"] = float(cam["focal_dist"] * rng.uniform(0.8, 1.2)); pt.SetCameraFocalDist(cam["focal_dist"])
+        if isinstance(out_img, str):
+            Wc, Hc = st["W"], st["H"]
+            out_img = pt.AllocOutImage() if out_img.endswith("2") and pt.GetResolution() == (Wc, Hc) else np.full((Hc, Wc, 3), 9, np.uint8)
+        if out_img is not None and tuple(np.asarray(out_img).shape[:2]) != (st["H"], st["W"]): out_img = np.full((st["H"], st["W"], 3), 9, np.uint8)
+        if os.environ.get("SOAK_VERBOSE"): print(f"  seed {seed} stage {stage} op {op} st {st} out {None if out_img is None else (type(out_img).__name__, np.asarray(out_img).shape, hex(np.asarray(out_img).ctypes.data))}", flush=True)
+        pt.SetOutImage(out_img)
         pt.ResetImage()
         total = int(rng.integers(1, 9)); done = 0
         while done < total:
@@ -59,13 +70,16 @@ for k in range(count):
         got = pt.ReadAccumulation()
         o = OB.Oracle(pt.StagedScene())
         ocam = OB.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
-        ref, _ = o.render(ocam, st["W"], st["H"], st["D"], 0, total, st["seed"], want_rgb8=False)
+        ref, ref8 = o.render(ocam, st["W"], st["H"], st["D"], 0, total, st["seed"])
         o.close()
         stages += 1
+        if out_img is not None and not np.array_equal(np.asarray(out_img), ref8):
+            bad += 1
+            print(f"HAND-OFF MISMATCH seed {seed} {name} stage {stage} op {op} state {st} buffer {type(out_img).__name__}", flush=True)
         if err or got.shape != ref.shape or not np.array_equal(got, ref):
             bad += 1
             print(f"MISMATCH seed {seed} {name} stage {stage} op {op} state {st} aperture {cam['aperture']} err '{err}'", flush=True)
-    pt.close(); other.close()
+    pt.SetOutImage(None); pt.close(); other.close(); out_img = None
     if k % 20 == 0: print(f"seed {seed} done [{time.time() - t0:.0f} s]", flush=True)
 print("stages", stages, "mismatches:", bad)
 sys.exit(1 if bad else 0)
