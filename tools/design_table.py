@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Prints the measurement table of DESIGN.md section 7 from profiles/r02/ (bench lines, counter summaries)."""
+"""Prints the measurement table of DESIGN.md section 7 from profiles/r03/ (bench lines, counter summaries)."""
 import json
 import os
 import sys
 
-d = sys.argv[1] if len(sys.argv) > 1 else "profiles/r02"
+d = sys.argv[1] if len(sys.argv) > 1 else "profiles/r03"
 
 
 def load(name):

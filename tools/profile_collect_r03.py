@@ -91,13 +91,15 @@ for f in glob.glob(f"{src}/ktrace_overlap_C2/**/*_kernel_trace.csv", recursive=T
 rows.sort()
 if len(rows) > 8:
     durs = [(e - s) / 1e6 for s, e in rows]
-    longest = max(durs)
-    full = [(s, e) for (s, e), d in zip(rows, durs) if d >= 0.5 * longest]
+    med = sorted(durs)[len(durs) // 2]
+    full = [(s, e) for (s, e), d in zip(rows, durs) if d >= 0.5 * med]      # (not the 1-spp set-up launch)
     pairs = []
     for (s0, e0), (s1, e1) in zip(full[:-1], full[1:]):
         pairs.append({"launch_ms": round((e0 - s0) / 1e6, 4), "next_start_after_this_start_ms": round((s1 - s0) / 1e6, 4),
                       "overlap_ms": round(max(0, e0 - s1) / 1e6, 4)})
-    steady = pairs[len(pairs) // 4:]
+    # steady state: the timed loop's launches (the first ones still share the chip with the warm-up; the last three are
+    # bench.py's isolated launches, overlap = 0, which start after their predecessor has ended)
+    steady = [p for p in pairs[len(pairs) // 4:] if p["overlap_ms"] > 0.0 and p["launch_ms"] < 1.5 * med]
     ov = {"command": "rocprofv3 --kernel-trace -- python3 bench.py --config C2 --steps 40 --warmup 5 --no-cpu-baseline --no-other-configs --no-parity --no-contracted --no-interactive   (overlap option at its default, 1)",
           "kernel": "trace_kernel<false, true>", "full_launches": len(full),
           "mean_launch_ms": round(sum(p["launch_ms"] for p in steady) / len(steady), 4),
