@@ -367,6 +367,34 @@ def test_headline_config_whole_frame_at_full_sample_count(tmp_path, oracle_mod):
     pt.close()
 
 
+@pytest.mark.parametrize("cfg,spp", [("C3", 12), ("C4", 12), ("C5", 6)])
+def test_bvh_configs_whole_frame(tmp_path, oracle_mod, cfg, spp):
+    """EVERY pixel of the BVH-walk configs at their full resolution (the sample count reduced so that the oracle needs seconds,
+    not minutes, of the box's host cores): thin lens + textures + opacity (C3), 70 k triangles (C4), 1 M triangles at depth 12
+    on the device-built tree (C5) - float accumulator and RGB8 against the oracle, bit for bit.  (The spot checks above run
+    the full sample counts on a spread of tiles; tools/fullframe_check.py is the one-off at 64-128 spp.)"""
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
+    pts, scene, _ = S.build_config(cfg, str(tmp_path))
+    pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(41)
+    cam = camera_from_scene(scene)
+    if scene.pinhole:
+        pt.SetCameraAperture(0.0); cam["aperture"] = 0.0
+    W, H = pt.GetResolution(); Dp = pt.GetTraceDepth()
+    out = np.zeros((H, W, 3), np.uint8); pt.SetOutImage(out)
+    pt.RenderFrames(spp)
+    assert pt.LastError() == "" and pt.GetSamples() == spp
+    got = pt.ReadAccumulation()
+    o = oracle_mod.Oracle(pt.StagedScene())
+    ocam = oracle_mod.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+    ref, ref8 = o.render(ocam, W, H, Dp, 0, spp, 41)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(out, ref8)
+    assert (ref != 0).any(axis=2).mean() > 0.1
+    pt.SetOutImage(None)
+    pt.close()
+
+
 def test_c5_tile_split_over_8_ranks_on_one_gpu(tmp_path, oracle_mod):
     """BASELINE configs[4]'s shape - the 1 M-triangle frame tile-split over 8 ranks and gathered - with this one GPU playing
     every rank in turn: each rank's share is rendered (ptk_set_tile), packed by the exchange's pack kernel, and the eight
