@@ -426,6 +426,37 @@ __device__ __forceinline__ bool tri_test_pair(const PT& P, Walk& W, Walk& WS, co
     return oks & (tri != WS.occl_tri);
 }
 
+// What the walk loop reads of the launch parameters, held in SGPRs for the length of the loop.  The parameters themselves
+// live in the constant address space (trace_kernel), where a field is an s_load at its point of use - right for the hundreds of
+// fields-times-places outside the hot loop, wrong inside it: the compiler re-issued the loads of the node and triangle pointers
+// in EVERY walk iteration and waited for them before the node record could even be requested.  readfirstlane makes the
+// values opaque (not re-materialisable as loads).
+// (The pointers keep the GLOBAL address space through the integer round trip: a generic pointer would turn every record fetch
+// into a flat_load, which is slower and counts against the LDS counter as well.)
+#define PTK_GLOBAL __attribute__((address_space(1)))
+struct WalkParams {
+    const float4* nodes; const float4* tris; const float4* shade;
+    const int4* texinfo; const uint32_t* texels;
+    int tri_thr, shade_thr, gen_thr;
+};
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p)
+{
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (T*)(PTK_GLOBAL T*)(uintptr_t)(((uint64_t)hi << 32) | lo);        // integer -> GLOBAL pointer -> generic: the loads stay global_load
+}
+template <class PT>
+__device__ __forceinline__ WalkParams walk_params(const PT& P)
+{
+    WalkParams w;
+    w.nodes = uniform_ptr(P.nodes); w.tris = uniform_ptr(P.tris); w.shade = uniform_ptr(P.shade);
+    w.texinfo = uniform_ptr(P.texinfo); w.texels = uniform_ptr(P.texels);
+    w.tri_thr = __builtin_amdgcn_readfirstlane(P.tri_thr); w.shade_thr = __builtin_amdgcn_readfirstlane(P.shade_thr);
+    w.gen_thr = __builtin_amdgcn_readfirstlane(P.gen_thr);
+    return w;
+}
+
 // One BVH step of a lane: up to TWO units of work - one triangle of the pending leaf (arm A) AND one
 // interior node (arm B).  A leaf reached by arm B is parked in the lane's one-entry triangle queue and the
 // descent continues with the next node from the stack, so the two arms overlap instead of alternating
@@ -979,10 +1010,14 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
     uint32_t ray = 0;
     int st = ST_NEED;               // every lane works, whatever its own pixel is
 
+    // (what the walk loop's exits read of the parameters, in SGPRs for the kernel's life: see WalkParams)
+    float4* const samples_u = uniform_ptr(P.samples);
+    const int num_nodes_u = __builtin_amdgcn_readfirstlane(P.num_nodes);
+    const float scene_bound_u = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(P.scene_bound)));
     // a finished path: its radiance goes to the sample buffer, the lane moves to its next sample
 #define PTK_FINISH_PATH()                                                                         \
     do {                                                                                          \
-        P.samples[out_idx] = make_float4(L.x, L.y, L.z, 0.0f);                                    \
+        samples_u[out_idx] = make_float4(L.x, L.y, L.z, 0.0f);                                    \
         st = ST_NEED;                                                                             \
     } while (0)
 
@@ -999,7 +1034,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
             if (STATS) cnt.shadow++;                                                              \
             if (!(hit_ && W.best.tri != W.occl_tri)) L = add(L, Tdi);                             \
             W.occl_tri = -1;                                                                      \
-            W.begin(W.ro, nextDir, P.num_nodes, stack, P.scene_bound);                                                  \
+            W.begin(W.ro, nextDir, num_nodes_u, stack, scene_bound_u);                                   \
         }                                                                                         \
         else if (!hit_) PTK_FINISH_PATH();              /* :550 miss -> black */                  \
         else st = ST_SHADE;                                                                       \
@@ -1110,6 +1145,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
             int ds = __builtin_amdgcn_readfirstlane(debt_shade), dg = __builtin_amdgcn_readfirstlane(debt_gen);
             unsigned long long m_tq = __ballot(W.tri_left > 0), m_nr = __ballot(W.node >= 0);
             bool want_shade = false, want_gen = false;
+            const WalkParams WP = walk_params(P);          // the loop's share of the parameters, in SGPRs
             do
             {
                 if (STATS) { const uint32_t nt = (uint32_t)__popcll(__ballot(st == ST_TRAV)); if (lane == 0) { cnt.walk_iters++; cnt.walk_lanes += nt; } }
@@ -1122,11 +1158,11 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 // is finished but for the parked leaf idle too long; a 4-deep leaf ring per lane made
                 // that worse, not better.)
                 const int n_tq = __popcll(m_tq), n_nr = __popcll(m_nr);
-                const bool run_tri_arm = (n_tq > 0) & ((n_nr == 0) | (n_tq * 8 >= P.tri_thr * n_nr));      // (bitwise: no scalar branches)
+                const bool run_tri_arm = (n_tq > 0) & ((n_nr == 0) | (n_tq * 8 >= WP.tri_thr * n_nr));      // (bitwise: no scalar branches)
                 if (STATS && lane == 0 && run_tri_arm) { cnt.tri_execs++; cnt.tri_lanes += (uint32_t)n_tq; }
                 if (st == ST_TRAV)
                 {
-                    walk_step<STATS, PTK_TRACE_BLOCK>(P, W, rng, ray, stack, cnt, run_tri_arm);
+                    walk_step<STATS, PTK_TRACE_BLOCK>(WP, W, rng, ray, stack, cnt, run_tri_arm);
                     if (W.done()) PTK_WALK_DONE();
                 }
                 m_tq = __ballot(W.tri_left > 0); m_nr = __ballot(W.node >= 0);
@@ -1138,8 +1174,8 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 const int nl = nt + ns + ng;
                 ds += ns; dg += ng;
                 // one exit test per iteration, which exit it was is sorted out after the loop
-                want_shade = (ns > 0) & (ds * 8 >= P.shade_thr * (nl - ns));
-                want_gen = (ng > 0) & (dg * 8 >= P.gen_thr * (nl - ng));
+                want_shade = (ns > 0) & (ds * 8 >= WP.shade_thr * (nl - ns));
+                want_gen = (ng > 0) & (dg * 8 >= WP.gen_thr * (nl - ng));
                 if (want_shade | want_gen | (nt == 0)) break;
             } while (true);
             if (want_shade) run_shade = true;
@@ -1526,6 +1562,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES_BVH) void trace_po
                 lit = (fl >> 16) & 1u;
                 jst = J_WALK;
             }
+            const WalkParams WP = walk_params(P);          // the loop's share of the parameters, in SGPRs (see trace_kernel)
             int next = 0, dg = 0;               // wave-uniform: next job to deal; lane-iterations spent waiting for a job
             bool stop = false;                  // wave-uniform; ONE loop exit and no `continue`: the loop's latch stays a scalar branch
             do
@@ -1588,11 +1625,11 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES_BVH) void trace_po
                     if (STATS && lane == 0) { cnt.walk_iters++; cnt.walk_lanes += (uint32_t)n_walk; }
                     // the triangle arm is voted as in trace_kernel
                     const int n_tq = __popcll(m_tq), n_nr = __popcll(m_nr);
-                    const bool run_tri_arm = (n_tq > 0) & ((n_nr == 0) | (n_tq * 8 >= P.tri_thr * n_nr));
+                    const bool run_tri_arm = (n_tq > 0) & ((n_nr == 0) | (n_tq * 8 >= WP.tri_thr * n_nr));
                     if (STATS && lane == 0 && run_tri_arm) { cnt.tri_execs++; cnt.tri_lanes += (uint32_t)n_tq; }
                     if (jst == J_WALK)
                     {
-                        walk_step<STATS, PTK_TRACE_BLOCK>(P, W, rng, ray, stack, cnt, run_tri_arm);
+                        walk_step<STATS, PTK_TRACE_BLOCK>(WP, W, rng, ray, stack, cnt, run_tri_arm);
                         if (W.done())
                         {
                             if (STATS) { cnt.rays++; cnt.max_nodes = max(cnt.max_nodes, cnt.cur_nodes); cnt.cur_nodes = 0; }
