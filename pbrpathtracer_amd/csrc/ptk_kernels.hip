@@ -462,17 +462,29 @@ __device__ __forceinline__ WalkParams walk_params(const PT& P)
 // descent continues with the next node from the stack, so the two arms overlap instead of alternating
 // (the wave executes both arms every iteration anyway).  The price is slightly later t-max tightening;
 // the result is unaffected (closest hit is order-independent).
-template <bool STATS, int STRIDE, class PT>
+struct NodeRec { float4 q0, q1, q2, q3; };      // one 64-byte node record in flight / in registers
+// the record of the node a lane will test next (a lane without a node reads the root - every such lane the same 64 bytes - which
+// costs less than a branch around the loads and zeroing sixteen registers for the lanes that skip them)
+template <class PT>
+__device__ __forceinline__ void request_node(const PT& P, const Walk& W, NodeRec& r)
+{
+    const float4* np = P.nodes + (size_t)max(W.node, 0) * NODE_F4;
+    r.q0 = ldg4(np); r.q1 = ldg4(np + 1); r.q2 = ldg4(np + 2); r.q3 = ldg4(np + 3);
+}
+// PIPELINED: the caller's loop keeps a node record in flight ACROSS iterations - `rec` was requested (request_node) before the
+// loop or at the end of the lane's previous step, and the record of the node this step ends on is requested before the step
+// returns, so its round trip also covers the loop's wave-uniform bookkeeping (ballots, debts, ~30 dependent scalar instructions)
+// instead of starting behind it.
+template <bool STATS, int STRIDE, bool PIPELINED = false, class PT>
 __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, uint32_t ray, int* stack, Counters& cnt,
-                                          const bool run_tri_arm = true)
+                                          const bool run_tri_arm = true, NodeRec* rec = nullptr)
 {
 #if PTK_NODE_PREFETCH
     // the node record of arm B is requested BEFORE arm A runs, so that its round trip overlaps arm A's loads and arithmetic
     // (one memory latency per iteration instead of two; the compiler would otherwise issue it after arm A's join)
-    // (unconditional: a lane without a node reads the root - every such lane the same 64 bytes - which is cheaper than
-    // a branch around the loads and zeroing sixteen registers for the lanes that skip them)
-    const float4* np = P.nodes + (size_t)max(W.node, 0) * NODE_F4;
-    const float4 q0 = ldg4(np), q1 = ldg4(np + 1), q2 = ldg4(np + 2), q3 = ldg4(np + 3);
+    NodeRec here;
+    if (PIPELINED) here = *rec; else request_node(P, W, here);
+    const float4 q0 = here.q0, q1 = here.q1, q2 = here.q2, q3 = here.q3;
     asm volatile("" ::: "memory");
 #endif
     if (run_tri_arm && W.tri_left > 0)                    // ---- arm A: one triangle
@@ -566,6 +578,7 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
         W.tri_left = (code & 7) + 1;
         W.node = W.template pop<STRIDE>(stack);
     }
+    if (PIPELINED) request_node(P, W, *rec);                    // for this lane's next step (a finished walk asks for the root: where its next ray starts)
 }
 
 // hemisphere / lobe sampler, pathtracer.cpp:606-611 (:618-623 lobe form): see oracle sample_about()
@@ -1146,6 +1159,8 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
             unsigned long long m_tq = __ballot(W.tri_left > 0), m_nr = __ballot(W.node >= 0);
             bool want_shade = false, want_gen = false;
             const WalkParams WP = walk_params(P);          // the loop's share of the parameters, in SGPRs
+            NodeRec nrec;
+            request_node(WP, W, nrec);                     // the walk keeps one node record in flight across iterations (walk_step)
             do
             {
                 if (STATS) { const uint32_t nt = (uint32_t)__popcll(__ballot(st == ST_TRAV)); if (lane == 0) { cnt.walk_iters++; cnt.walk_lanes += nt; } }
@@ -1162,7 +1177,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
                 if (STATS && lane == 0 && run_tri_arm) { cnt.tri_execs++; cnt.tri_lanes += (uint32_t)n_tq; }
                 if (st == ST_TRAV)
                 {
-                    walk_step<STATS, PTK_TRACE_BLOCK>(WP, W, rng, ray, stack, cnt, run_tri_arm);
+                    walk_step<STATS, PTK_TRACE_BLOCK, true>(WP, W, rng, ray, stack, cnt, run_tri_arm, &nrec);
                     if (W.done()) PTK_WALK_DONE();
                 }
                 m_tq = __ballot(W.tri_left > 0); m_nr = __ballot(W.node >= 0);
