@@ -14,6 +14,8 @@ ctx = pt.context()
 for kv in os.environ.get("PTK_OPTS", "").split(","):
     if "=" in kv:
         k, v = kv.split("="); ctx.set_option(k, float(v))
+if any(k in os.environ.get("PTK_OPTS", "") for k in ("device_build", "bvh_")):
+    pt.BuildBVH(); pt.RenderFrames(1)                 # builder options take effect at the next upload
 print("bvh", ctx.bvh_info(), ctx.bvh_layout())
 ctx.set_option("overlap", 0)
 for rep in range(int(os.environ.get("PTK_PROBE_REPS", "3"))):
