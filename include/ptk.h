@@ -213,7 +213,7 @@ int ptk_probe_unpack(ptk_ctx* ctx, int world, const float* host_packed /* all ra
  * "flat" = 0/1, scenes of <= 16 triangles skip the BVH walk and test
  * every triangle with scalar loads (default 1), "flat_shade_weight" / "flat_gen_weight" = its block-choice
  * weights in eighths (defaults 8 / 64); "pass_bytes" = HBM
- * budget of the sample buffer between the trace and accumulate kernels (default 4 GiB);
+ * budget of the sample buffer between the trace and accumulate kernels (default 16 GiB; there are two such buffers at most);
  * "shade_threshold" / "gen_threshold" = scheduling lambdas of the wave state machine in eighths
  * (cost of the shading / camera-ray block relative to one BVH walk step; defaults: shading 200 for
  * trees of depth <= 4, else 68, or 46 for trees of 131 072 nodes and more (0 = this automatic choice), camera rays 16);

@@ -106,7 +106,7 @@ def test_many_spp_chunks_and_passes(ctx, oracle_mod):
     ctx.set_option("pass_bytes", 1 << 20); ctx.set_option("chunk", 5)
     ctx.reset(); ctx.render(0, 37, 5)
     again = ctx.read_accum()
-    ctx.set_option("pass_bytes", float(4 << 30)); ctx.set_option("chunk", 0)
+    ctx.set_option("pass_bytes", float(16 << 30)); ctx.set_option("chunk", 0)
     assert np.array_equal(again, got)
 
 
