@@ -479,7 +479,7 @@ int ptk_create(ptk_ctx** out, int device_ordinal)
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0)
-            c->resident_waves = cus * 16;        // 4 SIMDs x 4 waves of trace_kernel (112-114 VGPRs) per CU
+            c->resident_waves = cus * 16;        // 4 SIMDs x 4 waves of the BVH trace kernel per CU (launch_trace scales it to x 5 for the FLAT kernel)
         if (cus > 0) c->num_cus = cus;
     }
     if (hipMalloc(&c->d_exit, sizeof(uint32_t)) != hipSuccess || hipMemset(c->d_exit, 0, sizeof(uint32_t)) != hipSuccess ||
