@@ -13,8 +13,11 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (PTK_LIB_PATH: developer knob for A/B builds of the kernels, tools/ab.sh; the product loads the in-tree library)
-LIB_PATH = os.environ.get("PTK_LIB_PATH") or os.path.join(_HERE, "libptk.so")
+# The product loads the in-tree library, nothing else.  Only tools/*.sh (A/B of two builds inside one GPU-box call) point the
+# binding at another build, and they have to say so twice: PTK_DEV_TOOLS=1 and PTK_LIB_PATH=<a libptk_*.so beside libptk.so>.
+LIB_PATH = os.path.join(_HERE, "libptk.so")
+if os.environ.get("PTK_DEV_TOOLS") == "1" and os.environ.get("PTK_LIB_PATH", "").startswith(os.path.join(_HERE, "libptk_")):
+    LIB_PATH = os.environ["PTK_LIB_PATH"]
 
 PTK_OK = 0
 PTK_TILE = 16

@@ -4,6 +4,7 @@
 # On the GPU box:                              bash tools/ab.sh run C4 64 [C5 64 ...]  (alternates A, B, A, B)
 set -e
 cd "$(dirname "$0")/.."
+export PTK_DEV_TOOLS=1
 if [ "$1" = build ]; then shift; make -C pbrpathtracer_amd/csrc -j8 OUT=../libptk_B.so BUILD=build_B EXTRA="$*" 2>&1 | grep -E "error|warning" || true; ls -la pbrpathtracer_amd/libptk_B.so; exit 0; fi
 shift
 while [ $# -ge 2 ]; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B through bench.py (consecutive batches overlapped, as the headline is measured): bash tools/ab_bench.sh C2 100 [C1 200 ...]
 cd "$(dirname "$0")/.."
+export PTK_DEV_TOOLS=1
 while [ $# -ge 2 ]; do
   for arm in A B A B; do
     if [ $arm = B ]; then export PTK_LIB_PATH=$PWD/pbrpathtracer_amd/libptk_B.so; else unset PTK_LIB_PATH; fi

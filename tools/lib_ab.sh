@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: A/B of library builds within ONE gpurun call: bash tools/lib_ab.sh "A B" C2 256 C4 64 ...   ("-" = libptk.so)
 cd "$(dirname "$0")/.."
+export PTK_DEV_TOOLS=1
 arms=$1; shift
 while [ $# -ge 2 ]; do
   for rep in 1 2; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PTK_DEV_TOOLS=1
 # GPU box: L2 hit rate / bytes that left the L2 for the trace kernel of one config, library builds side by side.
 #   bash tools/pmc_l2.sh <outdir-under-gpurun_out> C5 32 A -      ("-" = libptk.so)
 OUT=$PWD/gpurun_out/$1; ROOT=$PWD; CFG=$2; SPP=$3; shift 3
