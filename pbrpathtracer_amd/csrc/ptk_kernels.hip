@@ -266,7 +266,9 @@ struct Counters { uint32_t rays, shadow, nodes, tris, shaded, tex, walk_iters, w
 // stack[k * PTK_BLOCK].
 struct Walk {
     v3 ro, rd, inv;
-    v3 slack;                    // per axis: what the slab distances of any node of the scene can be off by for this ray (walk_step)
+    v3 cn, cf;                   // per axis: -(ro * inv + slack) and slack - ro * inv, the constant terms of a node's near / far slab
+                                 // distances for this ray; slack = what the slab arithmetic can be off by for any node (walk_step)
+    uint32_t sgnx, sgny, sgnz;   // per axis: all ones when the ray travels towards -axis (selects the near / far plane bytes with one v_bfi each)
     int node;
     int* top;                    // this lane's stack top in LDS (== its column's base when empty); unused by the FLAT kernel
     int tri_next, tri_left;      // pending leaf: records [tri_next, tri_next + tri_left) still to test
@@ -298,9 +300,19 @@ struct Walk {
         // steps span at most the scene, so per axis that is at most 2^-21 (|ro| + 3.1 scene_bound) |inv| - a property of the RAY,
         // computed here once instead of twelve instructions per node visited.  (In position units 5e-7 x the scene's size:
         // nothing next to a node's own extent until rays come from ~10^5 scene sizes away, where it is exactly what is needed.)
-        slack = V((fabsf(o.x) + scene_bound) * fabsf(inv.x) * 0x1p-21f, (fabsf(o.y) + scene_bound) * fabsf(inv.y) * 0x1p-21f,
-                  (fabsf(o.z) + scene_bound) * fabsf(inv.z) * 0x1p-21f);
+        const v3 slack = V((fabsf(o.x) + scene_bound) * fabsf(inv.x) * 0x1p-21f, (fabsf(o.y) + scene_bound) * fabsf(inv.y) * 0x1p-21f,
+                           (fabsf(o.z) + scene_bound) * fabsf(inv.z) * 0x1p-21f);
+        // ... and folded, with the ray's own share of B, into the constant of ONE fma per plane family and axis:
+        //   B -+ slack = origin * inv - ro * inv -+ slack = fma(origin, inv, cn | cf)
+        // (origin * inv - ro * inv instead of (origin - ro) * inv: the cancellation costs 2^-24 (|origin| + |ro|) |inv| at most,
+        // which the bound above was derived with - |origin - ro| <= |origin| + |ro| - so it is covered)
+        const v3 roi = V(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+        cn = V(-(roi.x + slack.x), -(roi.y + slack.y), -(roi.z + slack.z));
+        cf = V(slack.x - roi.x, slack.y - roi.y, slack.z - roi.z);
+#else
+        cn = V(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); cf = cn;
 #endif
+        sgnx = (uint32_t)(__float_as_int(inv.x) >> 31); sgny = (uint32_t)(__float_as_int(inv.y) >> 31); sgnz = (uint32_t)(__float_as_int(inv.z) >> 31);
         node = num_nodes > 0 ? 0 : NODE_EXIT;
         top = stack;
         tri_next = 0; tri_left = 0;
@@ -468,7 +480,8 @@ struct NodeRec { float4 q0, q1, q2, q3; };      // one 64-byte node record in fl
 template <class PT>
 __device__ __forceinline__ void request_node(const PT& P, const Walk& W, NodeRec& r)
 {
-    const float4* np = P.nodes + (size_t)max(W.node, 0) * NODE_F4;
+    // (a 32-bit byte offset from the wave-uniform base: the load takes its base from an SGPR pair, no 64-bit address arithmetic)
+    const float4* np = (const float4*)((const char*)P.nodes + (uint32_t)max(W.node, 0) * (uint32_t)(NODE_F4 * 16));
     r.q0 = ldg4(np); r.q1 = ldg4(np + 1); r.q2 = ldg4(np + 2); r.q3 = ldg4(np + 3);
 }
 // PIPELINED: the caller's loop keeps a node record in flight ACROSS iterations - `rec` was requested (request_node) before the
@@ -489,7 +502,7 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
 #endif
     if (run_tri_arm && W.tri_left > 0)                    // ---- arm A: one triangle
     {
-        const float4* tp = P.tris + (size_t)W.tri_next * TRI_F4;
+        const float4* tp = (const float4*)((const char*)P.tris + (uint32_t)W.tri_next * (uint32_t)(TRI_F4 * 16));
         float4 t0 = ldg4(tp), t1 = ldg4(tp + 1), t2 = ldg4(tp + 2);
         W.tri_next++; W.tri_left--;
         const bool stop = tri_test<STATS>(P, W, t0, t1, t2, rng, ray, cnt);
@@ -509,24 +522,19 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
         // (box tests are acceleration only - any conservative test gives the same closest hit - so fused
         // multiply-adds and approximate reciprocals are fine here; the grid boxes enclose the padded boxes)
         const float Ax = q0.w * W.inv.x, Ay = q1.x * W.inv.y, Az = q1.y * W.inv.z;
-        const float Bx = (q0.x - W.ro.x) * W.inv.x, By = (q0.y - W.ro.y) * W.inv.y, Bz = (q0.z - W.ro.z) * W.inv.z;
-#if PTK_ROBUST_BOXES
         // CONSERVATIVE for every ray, however far its origin: t = fma(q, A, B) is the sum of two possibly large terms, so its
-        // error is absolute - at most 2^-22 (|B| + 255 |A|) from the roundings of origin - ro, the two products, the 1-ulp
-        // reciprocal and the fma - i.e. a position error of ~6e-8 x the distance between the ray's origin and the node, which
-        // exceeds an 8-bit grid step once that distance is > 65 000 node extents (and Moeller-Trumbore's own decisions carry
-        // the same uncertainty, so no padding of the tree can stand in for it).  Near planes are taken that much (x 2) too
-        // early and far planes too late; found by tools/soak_bvh.py: two clusters of 1e-3 at +-1e3 gave tree-dependent hits.
-        // The bound is taken per RAY (Walk::begin: |B| <= (|ro| + scene bound) |inv|, 256 |A| <= 2.01 scene bound |inv|), not
-        // per node: six additions here instead of twelve instructions.
-        const float Bnx = Bx - W.slack.x, Bny = By - W.slack.y, Bnz = Bz - W.slack.z, Bfx = Bx + W.slack.x, Bfy = By + W.slack.y, Bfz = Bz + W.slack.z;
-#else
-        const float Bnx = Bx, Bny = By, Bnz = Bz, Bfx = Bx, Bfy = By, Bfz = Bz;
-#endif
+        // error is absolute - at most 2^-22 (|B| + 255 |A|) from the roundings of the products, the 1-ulp reciprocal and the
+        // fmas - i.e. a position error of ~6e-8 x the distance between the ray's origin and the node, which exceeds an 8-bit
+        // grid step once that distance is > 65 000 node extents (and Moeller-Trumbore's own decisions carry the same
+        // uncertainty, so no padding of the tree can stand in for it).  Near planes are taken that much (x 2) too early and far
+        // planes too late; found by tools/soak_bvh.py: two clusters of 1e-3 at +-1e3 gave tree-dependent hits.  The bound is
+        // taken per RAY (Walk::begin: |B| <= (|ro| + scene bound) |inv|, 256 |A| <= 2.01 scene bound |inv|) and folded into the
+        // ray's constants: six fused multiply-adds per node here (round 2: fifteen instructions).
+        const float Bnx = __builtin_fmaf(q0.x, W.inv.x, W.cn.x), Bny = __builtin_fmaf(q0.y, W.inv.y, W.cn.y), Bnz = __builtin_fmaf(q0.z, W.inv.z, W.cn.z);
+        const float Bfx = __builtin_fmaf(q0.x, W.inv.x, W.cf.x), Bfy = __builtin_fmaf(q0.y, W.inv.y, W.cf.y), Bfz = __builtin_fmaf(q0.z, W.inv.z, W.cf.z);
         // the ray enters a slab through the low plane when it travels in +axis, through the high plane otherwise:
         // pick the near / far plane bytes of all four children at once by the sign of the direction
-        const uint32_t mx = (uint32_t)(__float_as_int(W.inv.x) >> 31), my = (uint32_t)(__float_as_int(W.inv.y) >> 31),
-                       mz = (uint32_t)(__float_as_int(W.inv.z) >> 31);
+        const uint32_t mx = W.sgnx, my = W.sgny, mz = W.sgnz;
         const uint32_t lox = __float_as_uint(q2.z), loy = __float_as_uint(q2.w), loz = __float_as_uint(q3.x);
         const uint32_t hix = __float_as_uint(q3.y), hiy = __float_as_uint(q3.z), hiz = __float_as_uint(q3.w);
         const uint32_t nx = (hix & mx) | (lox & ~mx), fx = (lox & mx) | (hix & ~mx);
