@@ -297,18 +297,17 @@ struct Walk {
 #if PTK_ROBUST_BOXES
         // The slab arithmetic of walk_step, t = fma(q, A, B) with A = scale * inv and B = (origin - ro) * inv, is off by at most
         // 2^-21 (|B| + 256 |A|) (see there).  Every node origin lies inside the scene's padded bounds and a node's 255 grid
-        // steps span at most the scene, so per axis that is at most 2^-21 (|ro| + 3.1 scene_bound) |inv| - a property of the RAY,
+        // steps span at most the scene, so per axis that is at most 2^-21 (max |ro| + 3.1 scene_bound) |inv| - a property of the RAY,
         // computed here once instead of twelve instructions per node visited.  (In position units 5e-7 x the scene's size:
         // nothing next to a node's own extent until rays come from ~10^5 scene sizes away, where it is exactly what is needed.)
-        const v3 slack = V((fabsf(o.x) + scene_bound) * fabsf(inv.x) * 0x1p-21f, (fabsf(o.y) + scene_bound) * fabsf(inv.y) * 0x1p-21f,
-                           (fabsf(o.z) + scene_bound) * fabsf(inv.z) * 0x1p-21f);
+        const float r21 = (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + scene_bound) * 0x1p-21f;      // (one bound for the three axes)
+        const v3 slack = V(r21 * fabsf(inv.x), r21 * fabsf(inv.y), r21 * fabsf(inv.z));
         // ... and folded, with the ray's own share of B, into the constant of ONE fma per plane family and axis:
-        //   B -+ slack = origin * inv - ro * inv -+ slack = fma(origin, inv, cn | cf)
+        //   B -+ slack = origin * inv - ro * inv -+ slack = fma(origin, inv, cn | cf),   cn = fma(-ro, inv, -slack), cf = fma(-ro, inv, slack)
         // (origin * inv - ro * inv instead of (origin - ro) * inv: the cancellation costs 2^-24 (|origin| + |ro|) |inv| at most,
         // which the bound above was derived with - |origin - ro| <= |origin| + |ro| - so it is covered)
-        const v3 roi = V(o.x * inv.x, o.y * inv.y, o.z * inv.z);
-        cn = V(-(roi.x + slack.x), -(roi.y + slack.y), -(roi.z + slack.z));
-        cf = V(slack.x - roi.x, slack.y - roi.y, slack.z - roi.z);
+        cn = V(__builtin_fmaf(-o.x, inv.x, -slack.x), __builtin_fmaf(-o.y, inv.y, -slack.y), __builtin_fmaf(-o.z, inv.z, -slack.z));
+        cf = V(__builtin_fmaf(-o.x, inv.x, slack.x), __builtin_fmaf(-o.y, inv.y, slack.y), __builtin_fmaf(-o.z, inv.z, slack.z));
 #else
         cn = V(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); cf = cn;
 #endif
