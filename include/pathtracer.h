@@ -160,6 +160,10 @@ public:
     // The reference seeds one std::mt19937 from std::random_device (pathtracer.cpp:11); here the RNG
     // is counter-based and keyed on (seed, pixel, sample index), default seed 0.
     void SetSeed(uint64_t seed);
+    // SetOutImage for a display path that stays on the GPU: the 8-bit image (the layout of texData) is written into this
+    // OpenGL buffer object - the viewer's GL_PIXEL_UNPACK_BUFFER - instead of a host buffer (ptk_bind_gl_buffer, include/ptk.h;
+    // call with the viewer's OpenGL context current, as everything in main.cpp is).  0 or SetOutImage(ptr) switches back.
+    void SetOutGLBuffer(unsigned int gl_buffer);
     // One process per GPU: which device this instance drives, and which 16x16 pixel tiles it owns.
     void SetDevice(int ordinal);
     void SetTile(int rank, int world);

@@ -145,6 +145,19 @@ int ptk_resolve_rgb8(ptk_ctx* ctx, uint8_t* host_out);
  * (the caller reallocates texData then, main.cpp:3425-3446).  The buffer stays caller-owned; while bound, renders run on
  * the context's stream alone (each frame is waited for anyway). */
 int ptk_bind_out_image(ptk_ctx* ctx, uint8_t* host_out);
+/* The same hand-off without the PCIe hop, for a display path that lives on the GPU (N3: the viewer's frameTex ← texData upload,
+ * main.cpp:3026-3029, :3425-3446).  The accumulate kernel writes the 8-bit image - W*H*3 bytes, RGB, rows bottom-up, the layout
+ * of texData - into the bound DEVICE memory; ptk_synchronize waits for it.  One binding at a time: binding a host buffer, a
+ * device buffer or an OpenGL buffer replaces whatever was bound; NULL / 0 unbinds; ptk_set_frame with another resolution unbinds.
+ *   ptk_bind_out_device: any allocation of this context's GPU (hipMalloc, a torch tensor, imported external memory).
+ *   ptk_bind_gl_buffer:  an OpenGL buffer object of >= W*H*3 bytes (the viewer's pixel-unpack buffer), registered with
+ *     hipGraphicsGLRegisterBuffer and mapped only for the length of each ptk_render (HIP owns it between map and unmap; the
+ *     unmap is ordered behind the kernel that writes it, so a glTexSubImage2D from the buffer issued after ptk_render has
+ *     returned reads the finished frame).  Must be called on the thread whose OpenGL context is current; without one the
+ *     call fails with PTK_ERR_BAD_ARG (the library does not link OpenGL and never creates a context).
+ *     NOT exercised on hardware: the build boxes are headless (no display server, no EGL); only the error paths are tested. */
+int ptk_bind_out_device(ptk_ctx* ctx, void* device_rgb8);
+int ptk_bind_gl_buffer(ptk_ctx* ctx, unsigned int gl_buffer);
 /* Page-locked host memory for the hand-off buffer (what `new GLubyte[w*h*3]` is in main.cpp:3435): a
  * ptk_resolve_rgb8 into it is one DMA transfer instead of a staged copy.  Caller-owned, like texData:
  * release with ptk_host_free before the context that allocated it is destroyed or after - either order. */

@@ -4,7 +4,9 @@
 // Reference behaviour restated here (PathTracing/src/pathtracer.cpp): BuildBVH + light list :260-274,
 // setters :297-360, frame set-up arithmetic of RenderFrame :755-766, reset :745-751.
 #include <hip/hip_runtime.h>
+#include <hip/hip_gl_interop.h>
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -69,6 +71,11 @@ struct ptk_ctx {
     uint8_t* out_host = nullptr; uint8_t* out_host_dev = nullptr;
     bool out_registered = false;
     std::atomic<bool> out_full_next{ true };
+    // ... or a DEVICE buffer bound by ptk_bind_out_device, or an OpenGL buffer object registered by ptk_bind_gl_buffer (mapped
+    // for the length of each render: run_passes)
+    uint8_t* out_device = nullptr;
+    hipGraphicsResource_t gl_res = nullptr;
+    unsigned gl_buffer = 0;
     int rank = 0, world = 1;
 
     std::atomic<int> samples{ 0 };
@@ -281,8 +288,18 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
 void unbind_out_image(ptk_ctx* c)
 {
     if (c->out_registered && c->out_host) { (void)hipHostUnregister(c->out_host); (void)hipGetLastError(); }
+    if (c->gl_res) { (void)hipGraphicsUnregisterResource(c->gl_res); (void)hipGetLastError(); }
     c->out_host = nullptr; c->out_host_dev = nullptr; c->out_registered = false; c->out_full_next = true;
+    c->out_device = nullptr; c->gl_res = nullptr; c->gl_buffer = 0;
 }
+
+// An OpenGL buffer object is HIP's for the length of a render only: mapped before the first pass, unmapped (on the render
+// stream, so behind the accumulate kernel that writes it) on every way out of run_passes.
+struct GlMapping
+{
+    ptk_ctx* c; bool mapped = false;
+    ~GlMapping() { if (mapped) { (void)hipGraphicsUnmapResources(1, &c->gl_res, c->stream); (void)hipGetLastError(); } }
+};
 
 int owned_tiles(const RenderParams& p)
 {
@@ -321,10 +338,26 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         c->inputs_dirty = true;
     }
     p.pixel_rng = c->d_pixel_rng;
-    if (rgb8 == c->d_rgb8 && c->out_host_dev)
+    GlMapping glmap{ c };
+    uint8_t* handoff = nullptr;
+    if (rgb8 == c->d_rgb8)
+    {
+        handoff = c->out_host_dev ? c->out_host_dev : c->out_device;
+        if (!handoff && c->gl_res)
+        {
+            HIPCHK(c, hipGraphicsMapResources(1, &c->gl_res, c->stream));
+            glmap.mapped = true;
+            void* ptr = nullptr; size_t bytes = 0;
+            HIPCHK(c, hipGraphicsResourceGetMappedPointer(&ptr, &bytes, c->gl_res));
+            if (!ptr || bytes < (size_t)c->width * c->height * 3)
+                return fail(c, PTK_ERR_BAD_ARG, "the bound OpenGL buffer holds fewer than width * height * 3 bytes");
+            handoff = (uint8_t*)ptr;
+        }
+    }
+    if (handoff)
     {
         // (after the primary-hit cache has been brought up to date: a recomputed cache changes which pixels are always black)
-        p.rgb8_host = c->out_host_dev; p.rgb8_host_full = c->out_full_next.exchange(false) ? 1 : 0;
+        p.rgb8_host = handoff; p.rgb8_host_full = c->out_full_next.exchange(false) ? 1 : 0;
     }
     const int tiles = owned_tiles(p);
     c->last_passes = 0; c->last_launches = 0;
@@ -372,7 +405,7 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         const size_t need = per_sample * (size_t)chunk * num_chunks;
         // (a bound hand-off buffer means the caller waits for every frame: nothing to overlap, and one stream is two event
         // hops per frame less)
-        const bool overlap = c->opt_overlap != 0 && c->trace_stream[0] != nullptr && !(c->out_host_dev && rgb8 == c->d_rgb8);
+        const bool overlap = c->opt_overlap != 0 && c->trace_stream[0] != nullptr && !handoff;
         const int b = (int)(c->pass_counter & 1u);
         hipStream_t tstream = overlap ? c->trace_stream[b] : c->stream;
         if (overlap)
@@ -886,7 +919,8 @@ int ptk_reset(ptk_ctx* c)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::memset(c->out_host, 0, px * 3);
     }
-    c->out_full_next = true;
+    if (c->out_device) HIPCHK(c, hipMemsetAsync(c->out_device, 0, px * 3, c->stream));
+    c->out_full_next = true;                     // (a bound OpenGL buffer is rewritten whole by the next render)
     return PTK_OK;
 }
 
@@ -950,7 +984,7 @@ int ptk_bind_out_image(ptk_ctx* c, uint8_t* host_out)
 {
     if (!c) return PTK_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    if (host_out == c->out_host) return PTK_OK;
+    if (host_out == c->out_host && !c->out_device && !c->gl_res) return PTK_OK;
     if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));      // nothing may still be writing into the old buffer
     unbind_out_image(c);
     if (!host_out) return PTK_OK;
@@ -970,6 +1004,59 @@ int ptk_bind_out_image(ptk_ctx* c, uint8_t* host_out)
         }
         (void)hipGetLastError();                 // not lockable: ptk_resolve_rgb8 keeps copying, which is always correct
     }
+    c->out_full_next = true;
+    return PTK_OK;
+}
+
+int ptk_bind_out_device(ptk_ctx* c, void* device_rgb8)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (device_rgb8 && device_rgb8 == c->out_device) return PTK_OK;
+    if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+    unbind_out_image(c);
+    if (!device_rgb8) return PTK_OK;
+    if (c->width <= 0 || !c->d_rgb8) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, device_rgb8) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != c->device)
+    {
+        (void)hipGetLastError();
+        return fail(c, PTK_ERR_BAD_ARG, "ptk_bind_out_device: not a device allocation of this context's GPU");
+    }
+    c->out_device = (uint8_t*)device_rgb8;
+    HIPCHK(c, hipMemsetAsync(c->out_device, 0, (size_t)c->width * c->height * 3, c->stream));
+    c->out_full_next = true;
+    return PTK_OK;
+}
+
+int ptk_bind_gl_buffer(ptk_ctx* c, unsigned int gl_buffer)
+{
+    if (!c) return PTK_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (gl_buffer != 0 && gl_buffer == c->gl_buffer && c->gl_res) return PTK_OK;
+    if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+    unbind_out_image(c);
+    if (gl_buffer == 0) return PTK_OK;
+    if (c->width <= 0 || !c->d_rgb8) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    // Registration talks to the OpenGL driver through the calling thread's CURRENT context (the viewer's: main.cpp creates it
+    // before the path tracer renders anything).  The library does not link OpenGL: the process that calls this has it loaded,
+    // and a process without a current context gets an error here instead of a crash inside the runtime.
+    typedef void* (*current_ctx_fn)(void);
+    bool have_ctx = false;
+    for (const char* name : { "glXGetCurrentContext", "eglGetCurrentContext", "wglGetCurrentContext" })
+    {
+        current_ctx_fn fn = (current_ctx_fn)dlsym(RTLD_DEFAULT, name);
+        if (fn && fn() != nullptr) { have_ctx = true; break; }
+    }
+    if (!have_ctx) return fail(c, PTK_ERR_BAD_ARG, "ptk_bind_gl_buffer: no OpenGL context is current on the calling thread");
+    hipGraphicsResource_t res = nullptr;
+    const hipError_t e = hipGraphicsGLRegisterBuffer(&res, gl_buffer, hipGraphicsRegisterFlagsNone);
+    if (e != hipSuccess || !res)
+    {
+        (void)hipGetLastError();
+        return fail(c, PTK_ERR_HIP, std::string("hipGraphicsGLRegisterBuffer: ") + hipGetErrorString(e));
+    }
+    c->gl_res = res; c->gl_buffer = gl_buffer;
     c->out_full_next = true;
     return PTK_OK;
 }

@@ -28,7 +28,7 @@ _f = C.POINTER(C.c_float)
 HOST_SYMBOLS = [
     "pth_create", "pth_destroy", "pth_load_object", "pth_set_material", "pth_set_texture", "pth_build_bvh",
     "pth_reset_image", "pth_clear_scene", "pth_get_samples", "pth_get_triangle_count", "pth_get_trace_depth",
-    "pth_set_trace_depth", "pth_set_out_image", "pth_set_resolution", "pth_get_resolution", "pth_num_objects",
+    "pth_set_trace_depth", "pth_set_out_image", "pth_set_out_gl_buffer", "pth_set_resolution", "pth_get_resolution", "pth_num_objects",
     "pth_num_elements", "pth_set_camera", "pth_set_projection", "pth_set_focal_dist", "pth_set_aperture",
     "pth_render_frame", "pth_exit", "pth_set_seed", "pth_set_tile", "pth_render_frames", "pth_read_accum",
     "pth_last_error", "pth_context", "pth_staged_scene", "pth_load_scene_file", "pth_pts_roundtrip",
@@ -57,6 +57,7 @@ def lib() -> C.CDLL:
     L.pth_num_elements.restype = i32; L.pth_num_elements.argtypes = [vp, i32]
     L.pth_set_trace_depth.restype = None; L.pth_set_trace_depth.argtypes = [vp, i32]
     L.pth_set_out_image.restype = None; L.pth_set_out_image.argtypes = [vp, vp]
+    L.pth_set_out_gl_buffer.restype = None; L.pth_set_out_gl_buffer.argtypes = [vp, C.c_uint]
     L.pth_set_resolution.restype = None; L.pth_set_resolution.argtypes = [vp, i32, i32]
     L.pth_get_resolution.restype = None; L.pth_get_resolution.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.pth_set_camera.restype = None; L.pth_set_camera.argtypes = [vp, _f, _f, _f]
@@ -165,6 +166,12 @@ class PathTracer:
             assert out.dtype == np.uint8 and out.flags.c_contiguous
         self._out = out
         self.L.pth_set_out_image(self.h, out.ctypes.data if out is not None else None)
+
+    def SetOutGLBuffer(self, gl_buffer: int):
+        """Extension: the 8-bit image goes into an OpenGL buffer object of the current context (0 switches back)."""
+        if gl_buffer:
+            self._out = None
+        self.L.pth_set_out_gl_buffer(self.h, int(gl_buffer))
 
     def AllocOutImage(self) -> np.ndarray:
         """A page-locked W*H*3 uint8 hand-off buffer (ptk_host_alloc) for SetOutImage: RenderFrame()'s copy into

@@ -69,7 +69,7 @@ SYMBOLS = [
     "ptk_bvh_info", "ptk_bvh_layout", "ptk_upload_timing", "ptk_download_bvh", "ptk_probe_hits", "ptk_probe_primary_dirs", "ptk_probe_math", "ptk_probe_direct", "ptk_host_alloc", "ptk_host_free",
     "ptk_packed_floats", "ptk_packed_layout", "ptk_comm_unique_id", "ptk_comm_init", "ptk_comm_destroy",
     "ptk_gather_wait", "ptk_read_gathered", "ptk_gathered_device_ptr", "ptk_probe_pack", "ptk_probe_unpack",
-    "ptk_bind_out_image", "ptk_comm_info",
+    "ptk_bind_out_image", "ptk_bind_out_device", "ptk_bind_gl_buffer", "ptk_comm_info",
 ]
 
 
@@ -114,6 +114,8 @@ def load() -> C.CDLL:
     L.ptk_comm_destroy.argtypes = [vp]
     L.ptk_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.ptk_bind_out_image.argtypes = [vp, vp]
+    L.ptk_bind_out_device.argtypes = [vp, vp]
+    L.ptk_bind_gl_buffer.argtypes = [vp, C.c_uint]
     L.ptk_gather_wait.argtypes = [vp]
     L.ptk_read_gathered.argtypes = [vp, vp]
     L.ptk_gathered_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -321,6 +323,14 @@ class Context:
             return
         assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and out.size == self.width * self.height * 3
         self._chk(self.L.ptk_bind_out_image(self.h, out.ctypes.data_as(C.c_void_p)), "ptk_bind_out_image")
+
+    def bind_out_device(self, device_ptr):
+        """ptk_bind_out_device: the address of W*H*3 bytes of this GPU's memory (e.g. a torch uint8 tensor's data_ptr()) or None."""
+        self._chk(self.L.ptk_bind_out_device(self.h, C.c_void_p(device_ptr) if device_ptr else None), "ptk_bind_out_device")
+
+    def bind_gl_buffer(self, gl_buffer: int):
+        """ptk_bind_gl_buffer: an OpenGL buffer object of the calling thread's current context (0 unbinds)."""
+        self._chk(self.L.ptk_bind_gl_buffer(self.h, int(gl_buffer)), "ptk_bind_gl_buffer")
 
     def gather_accum(self, root: int = 0, comm=None):
         self._chk(self.L.ptk_gather_accum(self.h, comm, root), "ptk_gather_accum")

@@ -315,6 +315,83 @@ def test_bound_handoff_buffer_tracks_every_frame(tmp_path, oracle_mod):
         del out, out2
 
 
+def test_device_resident_handoff_buffer(tmp_path):
+    """ptk_bind_out_device (N3 without the PCIe hop: the frameTex <- texData upload of main.cpp:3026-3029 for a display path
+    that lives on the GPU): the accumulate kernel's 8-bit image lands in a caller-owned DEVICE buffer - here a torch tensor -
+    and equals the device's resolved frame after every render, through camera moves, resets and a new resolution; host
+    memory, another binding and a resolution change are handled as documented."""
+    import torch
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer
+    pts, scene, _ = S.build_config("C1", str(tmp_path), width=100, height=76, depth=4)       # (a row of 300 bytes: dword rows)
+    pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(4); pt.SetCameraAperture(0.0)
+    W, H = pt.GetResolution()
+    pt.RenderFrame()
+    ctx = pt.context()
+    buf = torch.full((H, W, 3), 99, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.bind_out_device(buf.data_ptr())
+    for frame in range(9):
+        if frame == 3:
+            pt.SetCamera((0.6, 0.2, -3.5), (-0.15, -0.05, 1.0), (0, 1, 0))
+        if frame == 6:
+            pt.ResetImage()
+        pt.RenderFrame()
+        assert pt.LastError() == ""
+        ctx.synchronize()
+        dev = ctx.resolve_rgb8()
+        assert np.array_equal(buf.cpu().numpy(), dev), frame
+        if frame == 6:
+            assert pt.GetSamples() == 1
+    assert dev.any()
+    # an odd row length (the byte path of the accumulate kernel) and an offset, unaligned target
+    pt.SetResolution((67, 41)); pt.ResetImage(); pt.RenderFrame()
+    before = buf.cpu().numpy().copy()
+    assert np.array_equal(before, dev)                                  # the new resolution dropped the binding
+    raw = torch.zeros(67 * 41 * 3 + 8, dtype=torch.uint8, device="cuda:0"); torch.cuda.synchronize()
+    ctx = pt.context(); ctx.bind_out_device(raw.data_ptr() + 1)
+    pt.RenderFrame(); pt.RenderFrame(); ctx.synchronize()
+    got = raw.cpu().numpy()
+    assert np.array_equal(got[1:1 + 67 * 41 * 3].reshape(41, 67, 3), ctx.resolve_rgb8()) and got[0] == 0 and not got[1 + 67 * 41 * 3:].any()
+    # a host buffer takes the binding over; unbinding leaves the device buffer alone
+    out = np.zeros((41, 67, 3), np.uint8)
+    pt.SetOutImage(out); pt.RenderFrame()
+    assert np.array_equal(out, ctx.resolve_rgb8()) and np.array_equal(raw.cpu().numpy(), got)
+    pt.SetOutImage(None); pt.RenderFrame()
+    # not device memory / nothing bound yet: errors, and the context goes on working
+    from pbrpathtracer_amd import ptk
+    host = np.zeros(67 * 41 * 3, np.uint8)
+    with pytest.raises(ptk.PtkError, match="not a device allocation"):
+        ctx.bind_out_device(host.ctypes.data)
+    ctx.bind_out_device(None)
+    pt.RenderFrame()
+    assert pt.LastError() == ""
+    pt.close()
+
+
+def test_gl_buffer_binding_needs_a_current_context(tmp_path):
+    """ptk_bind_gl_buffer / PathTracer::SetOutGLBuffer on a headless box: no OpenGL context is current, so the binding is
+    refused with an error (never a crash inside the runtime) and rendering goes on into the library's own image.  The
+    mapped path itself (hipGraphicsMapResources -> the same device hand-off as ptk_bind_out_device -> unmap) cannot run
+    here: NOT exercised on hardware."""
+    from pbrpathtracer_amd import ptk
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer
+    pts, scene, _ = S.build_config("C1", str(tmp_path), width=64, height=48, depth=3)
+    pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(1)
+    pt.RenderFrame()
+    ctx = pt.context()
+    ref = ctx.resolve_rgb8()
+    with pytest.raises(ptk.PtkError, match="no OpenGL context is current"):
+        ctx.bind_gl_buffer(7)
+    ctx.bind_gl_buffer(0)                                               # unbinding nothing is fine
+    pt.SetOutGLBuffer(7); pt.RenderFrame()
+    assert "no OpenGL context" in pt.LastError()
+    pt.SetOutGLBuffer(0); pt.ResetImage(); pt.RenderFrame()
+    assert np.array_equal(ctx.resolve_rgb8(), ref)
+    pt.close()
+
+
 @pytest.mark.parametrize("cfg,world", [("C1", 1), ("C2", 97), ("C3", 149), ("C4", 499), ("C5", 1999)])
 def test_full_size_spot_check_against_oracle(tmp_path, oracle_mod, cfg, world):
     """The BASELINE configs at their FULL size and sample count (persistent waves, live-quadrant list, two passes for
