@@ -164,6 +164,8 @@ public:
     // OpenGL buffer object - the viewer's GL_PIXEL_UNPACK_BUFFER - instead of a host buffer (ptk_bind_gl_buffer, include/ptk.h;
     // call with the viewer's OpenGL context current, as everything in main.cpp is).  0 or SetOutImage(ptr) switches back.
     void SetOutGLBuffer(unsigned int gl_buffer);
+    // ... or into W*H*3 bytes of this GPU's memory (ptk_bind_out_device); NULL or SetOutImage(ptr) switches back.
+    void SetOutDeviceImage(void* device_rgb8);
     // One process per GPU: which device this instance drives, and which 16x16 pixel tiles it owns.
     void SetDevice(int ordinal);
     void SetTile(int rank, int world);

@@ -33,6 +33,7 @@ int  pth_get_trace_depth(pth_tracer* t);
 void pth_set_trace_depth(pth_tracer* t, int depth);
 void pth_set_out_image(pth_tracer* t, uint8_t* out);      /* caller-owned W*H*3 buffer (may be NULL) */
 void pth_set_out_gl_buffer(pth_tracer* t, unsigned int gl_buffer);   /* SetOutGLBuffer (extension): 0 switches back */
+void pth_set_out_device_image(pth_tracer* t, void* device_rgb8);      /* SetOutDeviceImage (extension): NULL switches back */
 void pth_set_resolution(pth_tracer* t, int w, int h);
 void pth_get_resolution(pth_tracer* t, int* w, int* h);
 int  pth_num_objects(pth_tracer* t);

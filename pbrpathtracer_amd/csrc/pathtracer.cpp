@@ -280,6 +280,7 @@ struct PathTracer::Impl {
     GLubyte* out_img = 0;
     GLubyte* bound_img = 0;             // what ptk_bind_out_image holds (bound lazily: binding needs the frame)
     unsigned out_gl = 0, bound_gl = 0;  // SetOutGLBuffer: an OpenGL buffer object instead of a host buffer
+    void* out_dev = 0; void* bound_dev = 0;   // SetOutDeviceImage: a device buffer instead of a host buffer
     bool bind_dirty = true;             // the library may have dropped the binding: call ptk_bind_out_image again, whatever the pointer
     int max_depth = 3;                                     // pathtracer.cpp:15
 
@@ -459,7 +460,7 @@ void PathTracer::ClearScene()                                           // :281-
     m->have_resolution = false;                                        // mTotalImg is freed (:292-294)
 }
 
-void PathTracer::SetOutImage(GLubyte* out) { m->out_img = out; if (out) m->out_gl = 0; }       // :297-300
+void PathTracer::SetOutImage(GLubyte* out) { m->out_img = out; if (out) { m->out_gl = 0; m->out_dev = 0; } }       // :297-300
 
 void PathTracer::SetResolution(const glm::ivec2& res)                  // :302-306
 {
@@ -535,13 +536,14 @@ void PathTracer::RenderFrames(int count)
         m->frame_dirty = false;
         m->bind_dirty = true;                                           // (a new resolution unbinds the hand-off buffer: say again what is bound)
     }
-    if (m->bind_dirty || m->out_img != m->bound_img || m->out_gl != m->bound_gl)
+    if (m->bind_dirty || m->out_img != m->bound_img || m->out_gl != m->bound_gl || m->out_dev != m->bound_dev)
     {
         m->bind_dirty = false;
         // SetOutImage (:297-300): the 8-bit resolve goes straight into the caller's buffer from now on
         if (m->out_gl) m->note(ptk_bind_gl_buffer(m->ctx, m->out_gl));
+        else if (m->out_dev) m->note(ptk_bind_out_device(m->ctx, m->out_dev));
         else m->note(ptk_bind_out_image(m->ctx, m->out_img));
-        m->bound_img = m->out_img; m->bound_gl = m->out_gl;
+        m->bound_img = m->out_img; m->bound_gl = m->out_gl; m->bound_dev = m->out_dev;
     }
     if (m->need_reset)                                                 // :745-751
     {
@@ -554,14 +556,15 @@ void PathTracer::RenderFrames(int count)
     m->note(rc);
     m->samples = ptk_samples(m->ctx);
     if (rc == PTK_OK && m->out_img) m->note(ptk_resolve_rgb8(m->ctx, m->out_img));   // :802-812 into the caller's buffer
-    else if (rc == PTK_OK && m->out_gl) m->note(ptk_synchronize(m->ctx));             // RenderFrame() returns with the frame in the OpenGL buffer
+    else if (rc == PTK_OK && (m->out_gl || m->out_dev)) m->note(ptk_synchronize(m->ctx));   // RenderFrame() returns with the frame in the OpenGL / device buffer
 }
 
 void PathTracer::Exit() { if (m->ctx) ptk_request_exit(m->ctx); }      // :819-822
 
 // ---- extensions -----------------------------------------------------------------------------------------
 void PathTracer::SetSeed(uint64_t seed) { m->seed = seed; }
-void PathTracer::SetOutGLBuffer(unsigned int gl_buffer) { m->out_gl = gl_buffer; if (gl_buffer) m->out_img = 0; }
+void PathTracer::SetOutGLBuffer(unsigned int gl_buffer) { m->out_gl = gl_buffer; if (gl_buffer) { m->out_img = 0; m->out_dev = 0; } }
+void PathTracer::SetOutDeviceImage(void* device_rgb8) { m->out_dev = device_rgb8; if (device_rgb8) { m->out_img = 0; m->out_gl = 0; } }
 void PathTracer::SetDevice(int ordinal) { if (!m->ctx) m->device = ordinal; }
 void PathTracer::SetTile(int rank, int world)
 {

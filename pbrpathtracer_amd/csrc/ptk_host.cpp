@@ -65,6 +65,7 @@ int pth_get_trace_depth(pth_tracer* t) { return t->pt.GetTraceDepth(); }
 void pth_set_trace_depth(pth_tracer* t, int d) { t->pt.SetTraceDepth(d); }
 void pth_set_out_image(pth_tracer* t, uint8_t* out) { t->pt.SetOutImage(out); }
 void pth_set_out_gl_buffer(pth_tracer* t, unsigned int gl_buffer) { t->pt.SetOutGLBuffer(gl_buffer); }
+void pth_set_out_device_image(pth_tracer* t, void* device_rgb8) { t->pt.SetOutDeviceImage(device_rgb8); }
 void pth_set_resolution(pth_tracer* t, int w, int h) { t->pt.SetResolution(glm::ivec2(w, h)); }
 void pth_get_resolution(pth_tracer* t, int* w, int* h) { glm::ivec2 r = t->pt.GetResolution(); *w = r.x; *h = r.y; }
 int pth_num_objects(pth_tracer* t) { return (int)t->pt.GetLoadedObjects().size(); }

@@ -28,7 +28,7 @@ _f = C.POINTER(C.c_float)
 HOST_SYMBOLS = [
     "pth_create", "pth_destroy", "pth_load_object", "pth_set_material", "pth_set_texture", "pth_build_bvh",
     "pth_reset_image", "pth_clear_scene", "pth_get_samples", "pth_get_triangle_count", "pth_get_trace_depth",
-    "pth_set_trace_depth", "pth_set_out_image", "pth_set_out_gl_buffer", "pth_set_resolution", "pth_get_resolution", "pth_num_objects",
+    "pth_set_trace_depth", "pth_set_out_image", "pth_set_out_gl_buffer", "pth_set_out_device_image", "pth_set_resolution", "pth_get_resolution", "pth_num_objects",
     "pth_num_elements", "pth_set_camera", "pth_set_projection", "pth_set_focal_dist", "pth_set_aperture",
     "pth_render_frame", "pth_exit", "pth_set_seed", "pth_set_tile", "pth_render_frames", "pth_read_accum",
     "pth_last_error", "pth_context", "pth_staged_scene", "pth_load_scene_file", "pth_pts_roundtrip",
@@ -58,6 +58,7 @@ def lib() -> C.CDLL:
     L.pth_set_trace_depth.restype = None; L.pth_set_trace_depth.argtypes = [vp, i32]
     L.pth_set_out_image.restype = None; L.pth_set_out_image.argtypes = [vp, vp]
     L.pth_set_out_gl_buffer.restype = None; L.pth_set_out_gl_buffer.argtypes = [vp, C.c_uint]
+    L.pth_set_out_device_image.restype = None; L.pth_set_out_device_image.argtypes = [vp, vp]
     L.pth_set_resolution.restype = None; L.pth_set_resolution.argtypes = [vp, i32, i32]
     L.pth_get_resolution.restype = None; L.pth_get_resolution.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.pth_set_camera.restype = None; L.pth_set_camera.argtypes = [vp, _f, _f, _f]
@@ -172,6 +173,13 @@ class PathTracer:
         if gl_buffer:
             self._out = None
         self.L.pth_set_out_gl_buffer(self.h, int(gl_buffer))
+
+    def SetOutDeviceImage(self, device_ptr):
+        """Extension: the 8-bit image goes into W*H*3 bytes of this GPU's memory (an address, e.g. a torch uint8 tensor's
+        data_ptr(), kept alive by the caller); None switches back."""
+        if device_ptr:
+            self._out = None
+        self.L.pth_set_out_device_image(self.h, C.c_void_p(device_ptr) if device_ptr else None)
 
     def AllocOutImage(self) -> np.ndarray:
         """A page-locked W*H*3 uint8 hand-off buffer (ptk_host_alloc) for SetOutImage: RenderFrame()'s copy into

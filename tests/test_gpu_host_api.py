@@ -326,30 +326,30 @@ def test_device_resident_handoff_buffer(tmp_path):
     pts, scene, _ = S.build_config("C1", str(tmp_path), width=100, height=76, depth=4)       # (a row of 300 bytes: dword rows)
     pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(4); pt.SetCameraAperture(0.0)
     W, H = pt.GetResolution()
-    pt.RenderFrame()
-    ctx = pt.context()
+    ctx = None
     buf = torch.full((H, W, 3), 99, dtype=torch.uint8, device="cuda:0")
     torch.cuda.synchronize()
-    ctx.bind_out_device(buf.data_ptr())
+    pt.SetOutDeviceImage(buf.data_ptr())                                # (PathTracer::SetOutDeviceImage -> ptk_bind_out_device)
     for frame in range(9):
         if frame == 3:
             pt.SetCamera((0.6, 0.2, -3.5), (-0.15, -0.05, 1.0), (0, 1, 0))
         if frame == 6:
             pt.ResetImage()
-        pt.RenderFrame()
+        pt.RenderFrame()                                                # (returns with the frame in the buffer)
         assert pt.LastError() == ""
-        ctx.synchronize()
+        got = buf.cpu().numpy()
+        ctx = ctx or pt.context()
         dev = ctx.resolve_rgb8()
-        assert np.array_equal(buf.cpu().numpy(), dev), frame
+        assert np.array_equal(got, dev), frame
         if frame == 6:
             assert pt.GetSamples() == 1
     assert dev.any()
     # an odd row length (the byte path of the accumulate kernel) and an offset, unaligned target
+    pt.SetOutDeviceImage(None)                                          # (the caller's buffer has the old size: main.cpp:3425-3446)
     pt.SetResolution((67, 41)); pt.ResetImage(); pt.RenderFrame()
-    before = buf.cpu().numpy().copy()
-    assert np.array_equal(before, dev)                                  # the new resolution dropped the binding
+    assert np.array_equal(buf.cpu().numpy(), dev)                       # unbound: untouched
     raw = torch.zeros(67 * 41 * 3 + 8, dtype=torch.uint8, device="cuda:0"); torch.cuda.synchronize()
-    ctx = pt.context(); ctx.bind_out_device(raw.data_ptr() + 1)
+    ctx = pt.context(); ctx.bind_out_device(raw.data_ptr() + 1)          # (the C-ABI call itself)
     pt.RenderFrame(); pt.RenderFrame(); ctx.synchronize()
     got = raw.cpu().numpy()
     assert np.array_equal(got[1:1 + 67 * 41 * 3].reshape(41, 67, 3), ctx.resolve_rgb8()) and got[0] == 0 and not got[1 + 67 * 41 * 3:].any()

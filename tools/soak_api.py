@@ -33,7 +33,7 @@ for k in range(count):
         op = int(rng.integers(0, 8))
         # the hand-off buffer comes and goes, pageable (page-locked in place) or from AllocOutImage
         if rng.uniform() < 0.5:
-            kind = int(rng.integers(0, 3))
+            kind = int(rng.integers(0, 4))                # (3: a device buffer - a torch tensor - through SetOutDeviceImage)
             out_img = None if kind == 0 else "pending-%d" % kind
         if op == 0:
             cam["pos"] = (np.asarray(cam["pos"], np.float32) + rng.uniform(-0.3, 0.3, 3).astype(np.float32)); pt.SetCamera(cam["pos"], cam["dir"], cam["up"])
@@ -57,10 +57,12 @@ for k in range(count):
             cam["focal_dist"] = float(cam["focal_dist"] * rng.uniform(0.8, 1.2)); pt.SetCameraFocalDist(cam["focal_dist"])
         if isinstance(out_img, str):
             Wc, Hc = st["W"], st["H"]
-            out_img = pt.AllocOutImage() if out_img.endswith("2") and pt.GetResolution() == (Wc, Hc) else np.full((Hc, Wc, 3), 9, np.uint8)
-        if out_img is not None and tuple(np.asarray(out_img).shape[:2]) != (st["H"], st["W"]): out_img = np.full((st["H"], st["W"], 3), 9, np.uint8)
-        if os.environ.get("SOAK_VERBOSE"): print(f"  seed {seed} stage {stage} op {op} st {st} out {None if out_img is None else (type(out_img).__name__, np.asarray(out_img).shape, hex(np.asarray(out_img).ctypes.data))}", flush=True)
-        pt.SetOutImage(out_img)
+            if out_img.endswith("3"): out_img = torch.full((Hc, Wc, 3), 9, dtype=torch.uint8, device="cuda:0"); torch.cuda.synchronize()
+            else: out_img = pt.AllocOutImage() if out_img.endswith("2") and pt.GetResolution() == (Wc, Hc) else np.full((Hc, Wc, 3), 9, np.uint8)
+        if out_img is not None and tuple(out_img.shape[:2]) != (st["H"], st["W"]): out_img = np.full((st["H"], st["W"], 3), 9, np.uint8)
+        if os.environ.get("SOAK_VERBOSE"): print(f"  seed {seed} stage {stage} op {op} st {st} out {None if out_img is None else (type(out_img).__name__, tuple(out_img.shape))}", flush=True)
+        if torch.is_tensor(out_img): pt.SetOutDeviceImage(out_img.data_ptr())
+        else: pt.SetOutDeviceImage(None); pt.SetOutImage(out_img)
         pt.ResetImage()
         total = int(rng.integers(1, 9)); done = 0
         while done < total:
@@ -73,13 +75,13 @@ for k in range(count):
         ref, ref8 = o.render(ocam, st["W"], st["H"], st["D"], 0, total, st["seed"])
         o.close()
         stages += 1
-        if out_img is not None and not np.array_equal(np.asarray(out_img), ref8):
+        if out_img is not None and not np.array_equal(out_img.cpu().numpy() if torch.is_tensor(out_img) else np.asarray(out_img), ref8):
             bad += 1
             print(f"HAND-OFF MISMATCH seed {seed} {name} stage {stage} op {op} state {st} buffer {type(out_img).__name__}", flush=True)
         if err or got.shape != ref.shape or not np.array_equal(got, ref):
             bad += 1
             print(f"MISMATCH seed {seed} {name} stage {stage} op {op} state {st} aperture {cam['aperture']} err '{err}'", flush=True)
-    pt.SetOutImage(None); pt.close(); other.close(); out_img = None
+    pt.SetOutDeviceImage(None); pt.SetOutImage(None); pt.close(); other.close(); out_img = None
     if k % 20 == 0: print(f"seed {seed} done [{time.time() - t0:.0f} s]", flush=True)
 print("stages", stages, "mismatches:", bad)
 sys.exit(1 if bad else 0)
