@@ -263,6 +263,19 @@ def interactive_probe(pt, ctx, W, H, frames=200):
     ctx.synchronize()
     out["ms_per_RenderFrame"] = round((time.perf_counter() - t0) / frames * 1e3, 4)
     out["handoff"] = "8-bit resolve written by accumulate_kernel straight into the caller's page-locked buffer (ptk_bind_out_image); no copy command"
+    # ... and with the frame staying on the GPU (ptk_bind_out_device: what ptk_bind_gl_buffer maps the viewer's pixel-unpack buffer
+    # to - the OpenGL leg itself cannot run on a headless box)
+    import torch
+    dbuf = torch.zeros((H, W, 3), dtype=torch.uint8, device=f"cuda:{torch.cuda.current_device()}"); torch.cuda.synchronize()
+    pt.SetOutDeviceImage(dbuf.data_ptr())
+    for _ in range(10):
+        pt.RenderFrame()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        pt.RenderFrame()                        # (returns with the frame in the buffer)
+    out["with_device_handoff_ms"] = round((time.perf_counter() - t0) / frames * 1e3, 4)
+    out["device_frame_matches"] = bool(np.array_equal(dbuf.cpu().numpy(), ctx.resolve_rgb8()))
+    pt.SetOutDeviceImage(None)
     out["frame_matches_device"] = bool(np.array_equal(host, dev)) and bool(host.any())
     out["Msamples_per_s_with_handoff"] = round(W * H / out["with_handoff_ms"] / 1e3, 1)
     del pinned

@@ -1008,6 +1008,22 @@ int ptk_bind_out_image(ptk_ctx* c, uint8_t* host_out)
     return PTK_OK;
 }
 
+// The interactive loop waits for frames of a few hundred microseconds: poll the stream for a while before handing the wait to
+// the runtime, whose blocking wait costs tens of microseconds to wake up.
+static int wait_polled(ptk_ctx* c)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;)
+    {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return PTK_OK;
+        if (q != hipErrorNotReady) return fail(c, PTK_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PTK_OK;
+}
+
 int ptk_bind_out_device(ptk_ctx* c, void* device_rgb8)
 {
     if (!c) return PTK_ERR_BAD_ARG;
@@ -1072,16 +1088,7 @@ int ptk_resolve_rgb8(ptk_ctx* c, uint8_t* host_out)
         // render has filled the buffer since it was bound / reset).  The interactive loop waits for a frame of a few hundred
         // microseconds: poll the stream for a while before handing the wait to the runtime, whose blocking wait costs
         // tens of microseconds to wake up
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;)
-        {
-            const hipError_t q = hipStreamQuery(c->stream);
-            if (q == hipSuccess) return PTK_OK;
-            if (q != hipErrorNotReady) return fail(c, PTK_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-        }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        return PTK_OK;
+        return wait_polled(c);
     }
     HIPCHK(c, hipMemcpyAsync(host_out, c->d_rgb8, (size_t)c->width * c->height * 3, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1136,6 +1143,7 @@ int ptk_synchronize(ptk_ctx* c)
 {
     if (!c) return PTK_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->out_device || c->gl_res) return wait_polled(c);     // a frame of the interactive loop (device-resident hand-off)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PTK_OK;
 }
