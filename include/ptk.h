@@ -102,7 +102,9 @@ void ptk_destroy(ptk_ctx* ctx);
 /* replaces BuildBVH (pathtracer.cpp:260-274, mesh.cpp:169-211): stages the scene, builds the BVH (own builders; closest
  * hit is tree-independent) and leaves everything resident in HBM.  Scenes of >= 4096 triangles are built ON THE GPU - binned
  * SAH level by level, collapse to the 4-wide quantised nodes, record packing (csrc/bvh_device.hip); smaller ones, and any
- * scene whose device-built tree would not fit the traversal stack, by the host builder (option "device_build" = 0 forces it) */
+ * scene whose device-built tree would not fit the traversal stack, by the host builder (option "device_build" = 0 forces it).
+ * Limits (PTK_ERR_LIMIT): at most 89 478 485 triangles (the walk addresses its 48-byte records with 32-bit byte offsets),
+ * |coordinate| < 2^61, a tree that defers at most PTK_MAX_BVH_DEPTH entries (the host builder always meets that). */
 int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene);
 
 /* SetMaterial after BuildBVH (pathtracer.cpp:243-258): the reference's triangles point into the loaded materials, so an

@@ -605,6 +605,12 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
         return fail(c, PTK_ERR_BAD_ARG, "negative count in scene description");
     if (n > 0 && (!s->verts || !s->normals || !s->uvs || !s->tbn || !s->smoothing || !s->material || !s->materials))
         return fail(c, PTK_ERR_BAD_ARG, "null triangle/material array");
+    // (the walk addresses triangle and node records with 32-bit BYTE offsets from wave-uniform bases - ptk_kernels.hip
+    // request_node / walk_step - so a record array ends below 4 GiB: 89 478 485 triangles of 48 bytes; checked before anything
+    // reads the arrays.  The node array of such a scene, ~0.4 nodes of 64 bytes per triangle, stays below that by itself and is
+    // checked once it exists)
+    if ((uint64_t)n * (uint64_t)(TRI_F4 * sizeof(float4)) > 0xffffffffull)
+        return fail(c, PTK_ERR_LIMIT, "more triangles than the kernels' 32-bit record offsets address (89 478 485)");
     if (s->num_lights > 0 && !s->lights) return fail(c, PTK_ERR_BAD_ARG, "null light array");
     if (s->num_textures > 0 && (!s->textures || !s->texels)) return fail(c, PTK_ERR_BAD_ARG, "null texture array");
     for (int32_t i = 0; i < n; i++)
@@ -663,6 +669,8 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
         if (bvh.stack_need > PTK_MAX_BVH_DEPTH) return fail(c, PTK_ERR_LIMIT, "BVH needs more entries than the LDS traversal stack holds");
     }
     struct DevBvhGuard { DeviceBvh& d; bool armed; ~DevBvhGuard() { if (armed) { (void)hipFree(d.d_nodes); (void)hipFree(d.d_order); } } } dguard{ dbvh, on_device };
+    if ((uint64_t)(on_device ? dbvh.num_nodes : bvh.num_nodes) * (uint64_t)(NODE_F4 * sizeof(float4)) > 0xffffffffull)
+        return fail(c, PTK_ERR_LIMIT, "more BVH nodes than the kernels' 32-bit record offsets address");
 
     c->upload_ms[0] = ms_since(t_begin);
     const auto t_pack = std::chrono::steady_clock::now();

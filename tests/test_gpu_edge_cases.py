@@ -133,6 +133,9 @@ def test_bad_arguments_are_errors(ctx):
     bad["verts"][0, 0] = np.float32(np.nan)
     with pytest.raises(ptk.PtkError):
         ctx.upload_scene(bad)
+    # more triangles than the walk's 32-bit record offsets address: refused before any array is read (so the arrays here may be small)
+    d = ptk.scene_desc(ptk.normalise_arrays(a)); d.num_triangles = 89_478_486
+    assert ctx.L.ptk_upload_scene(ctx.h, ptk.C.byref(d)) == -4 and b"32-bit record offsets" in ctx.L.ptk_last_error(ctx.h)
     # ... and the camera position (ray origins): DESIGN.md, documented difference 7
     cam = _cam(z)
     for v in (np.float32(3e18), np.float32(np.inf), np.float32(np.nan)):
