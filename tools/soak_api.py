@@ -1,5 +1,6 @@
 """GPU box, one-off: random sequences of host-API calls on the drop-in PathTracer (camera, projection, lens, resolution, trace
-depth, seed, material edits after BuildBVH, sample batching, a second tracer on the same GPU) - after every stage the
+depth, seed, material edits after BuildBVH, another scene file into the same tracer, tile splits, Exit() with nothing in flight,
+the pooled kernel switched on and off, hand-off buffers of every kind coming and going, sample batching, a second tracer on the same GPU) - after every stage the
 accumulator must be the oracle's for the state the calls left behind.  python tools/soak_api.py [first_seed] [count]"""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,6 +9,7 @@ import numpy as np
 import torch  # noqa: F401
 from pbrpathtracer_amd import scenes as S
 from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
+from pbrpathtracer_amd import distributed as Dm
 from oracle import oracle_binding as OB
 OB.build()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -27,10 +29,10 @@ for k in range(count):
     pt = PathTracer(0); pt.LoadSceneFile(pts)
     other = PathTracer(0); other.LoadSceneFile(built["C1"][0])
     cam = camera_from_scene(scene)
-    st = dict(W=pt.GetResolution()[0], H=pt.GetResolution()[1], D=pt.GetTraceDepth(), seed=0)
+    st = dict(W=pt.GetResolution()[0], H=pt.GetResolution()[1], D=pt.GetTraceDepth(), seed=0, tile=(0, 1))
     out_img = None
     for stage in range(int(rng.integers(3, 8))):
-        op = int(rng.integers(0, 8))
+        op = int(rng.integers(0, 12))
         # the hand-off buffer comes and goes, pageable (page-locked in place) or from AllocOutImage
         if rng.uniform() < 0.5:
             kind = int(rng.integers(0, 4))                # (3: a device buffer - a torch tensor - through SetOutDeviceImage)
@@ -53,8 +55,22 @@ for k in range(count):
             objs = pt.GetLoadedObjects()
             ob = int(rng.integers(0, len(objs)))
             pt.SetMaterial(ob, int(rng.integers(0, max(1, objs[ob]))), m)
-        else:
+        elif op == 7:
             cam["focal_dist"] = float(cam["focal_dist"] * rng.uniform(0.8, 1.2)); pt.SetCameraFocalDist(cam["focal_dist"])
+        elif op == 8:
+            # another scene file into the same tracer (ClearScene + the loader's whole call sequence): resolution, depth and camera are the file's
+            name = cfgs[int(rng.integers(0, len(cfgs)))][0]
+            pts, scene, _ = built[name]
+            pt.ClearScene(); pt.LoadSceneFile(pts)
+            cam = camera_from_scene(scene)
+            st.update(W=pt.GetResolution()[0], H=pt.GetResolution()[1], D=pt.GetTraceDepth())
+        elif op == 9:
+            w = int(rng.integers(1, 6)); st["tile"] = (int(rng.integers(0, w)), w); pt.SetTile(*st["tile"])
+        elif op == 10:
+            pt.Exit()                                        # nothing in flight: must not disturb what follows
+        else:
+            c = pt.context(); pooled = bool(rng.integers(0, 2))
+            c.set_option("persistent", 1 if pooled else -1); c.set_option("pool", int(rng.choice([64, 128, 256])) if pooled else 0)
         if isinstance(out_img, str):
             Wc, Hc = st["W"], st["H"]
             if out_img.endswith("3"): out_img = torch.full((Hc, Wc, 3), 9, dtype=torch.uint8, device="cuda:0"); torch.cuda.synchronize()
@@ -72,10 +88,17 @@ for k in range(count):
         got = pt.ReadAccumulation()
         o = OB.Oracle(pt.StagedScene())
         ocam = OB.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
-        ref, ref8 = o.render(ocam, st["W"], st["H"], st["D"], 0, total, st["seed"])
+        ref, ref8 = o.render(ocam, st["W"], st["H"], st["D"], 0, total, st["seed"], rank=st["tile"][0], world=st["tile"][1])
         o.close()
         stages += 1
-        if out_img is not None and not np.array_equal(out_img.cpu().numpy() if torch.is_tensor(out_img) else np.asarray(out_img), ref8):
+        if st["tile"][1] > 1:                                # a rank of a split: only its own tiles are its business
+            own = Dm.tile_owner_mask(st["W"], st["H"], *st["tile"])[::-1]
+            got = np.where(own[..., None], got, 0); ref = np.where(own[..., None], ref, 0)
+            if out_img is not None:
+                h8 = out_img.cpu().numpy() if torch.is_tensor(out_img) else np.asarray(out_img)
+                if not np.array_equal(h8[own], ref8[own]):
+                    bad += 1; print(f"HAND-OFF MISMATCH (split) seed {seed} {name} stage {stage} op {op} state {st}", flush=True)
+        elif out_img is not None and not np.array_equal(out_img.cpu().numpy() if torch.is_tensor(out_img) else np.asarray(out_img), ref8):
             bad += 1
             print(f"HAND-OFF MISMATCH seed {seed} {name} stage {stage} op {op} state {st} buffer {type(out_img).__name__}", flush=True)
         if err or got.shape != ref.shape or not np.array_equal(got, ref):
