@@ -516,6 +516,151 @@ def tier_k_images(ref: Ref, tmp: str):
     save("tier_k_images.npz", names=np.array(names), **out)
 
 
+def tier_k_images_psd_pic(ref: Ref, tmp: str):
+    """Texture ingest, the two remaining stb_image formats: Photoshop PSD (composite image; stb_image.h:6002-6252) and Softimage
+    PIC (:6256-6470).  No imaging library writes these: the files are assembled here byte by byte from the format descriptions;
+    the expected RGBA8 - or the fact that Image::Load yields nothing - comes from the reference's stb_image."""
+    import struct
+    rng = np.random.default_rng(99)
+    W, H = 23, 11
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = np.stack([(xx * 11) % 256, (yy * 23) % 256, ((xx + 2 * yy) * 7) % 256], -1).astype(np.uint8)
+    base[3:8, 5:15] = rng.integers(0, 256, (5, 10, 3), dtype=np.uint8)
+    base[:, 17:] = base[:, 17:18]                                   # runs for the run-length coders
+    alpha = ((xx * 37 + yy * 91) % 256).astype(np.uint8)
+    alpha[0, :6] = [0, 255, 1, 254, 128, 127]; alpha[5:7, :] = 255; alpha[8, :] = 0
+    rgba = np.dstack([base, alpha])
+
+    def packbits(row, noop_every=0):
+        out = bytearray(); i = 0; n = len(row); k = 0
+        while i < n:
+            j = i
+            while j + 1 < n and row[j + 1] == row[i] and j - i < 127: j += 1
+            if j > i:
+                out += bytes([257 - (j - i + 1), row[i]]); i = j + 1
+            else:
+                j = i
+                while j + 1 < n and (j + 2 >= n or row[j + 1] != row[j + 2] or True) and row[j + 1] != row[j] and j - i < 127: j += 1
+                out += bytes([j - i]) + bytes(row[i:j + 1]); i = j + 1
+            k += 1
+            if noop_every and k % noop_every == 0: out += b"\x80"
+        return bytes(out)
+
+    def psd(planes, depth=8, mode=3, version=1, compression=0, channels=None, blocks=(b"", b"", b""), w=W, h=H, noop=0, raw_tail=None):
+        channels = len(planes) if channels is None else channels
+        hd = b"8BPS" + struct.pack(">H6xHIIHH", version, channels, h, w, depth, mode)
+        for b in blocks: hd += struct.pack(">I", len(b)) + b
+        hd += struct.pack(">H", compression)
+        if raw_tail is not None: return hd + raw_tail
+        if compression == 0:
+            body = b"".join((p.astype(">u2") if depth == 16 else p.astype(np.uint8)).tobytes() for p in planes)
+        else:
+            rows = [[packbits(bytes(p[y].astype(np.uint8).tobytes()), noop) for y in range(h)] for p in planes]
+            body = b"".join(struct.pack(">H", len(r)) for pr in rows for r in pr) + b"".join(r for pr in rows for r in pr)
+        return hd + body
+
+    cases = []
+    R, G, B, A = (rgba[..., k] for k in range(4))
+    cases.append(("psd_rgb8_raw", psd([R, G, B])))
+    cases.append(("psd_rgba8_raw_matte", psd([R, G, B, A])))
+    wide = lambda p: p.astype(np.uint16) * 257 - (p.astype(np.uint16) % 3)       # 16-bit samples whose low bytes differ
+    cases.append(("psd_rgb16_raw", psd([wide(R), wide(G), wide(B)], depth=16)))
+    cases.append(("psd_rgba16_raw_matte", psd([wide(R), wide(G), wide(B), wide(A)], depth=16)))
+    cases.append(("psd_rgb8_rle", psd([R, G, B], compression=1)))
+    cases.append(("psd_rgba8_rle_noop_matte", psd([R, G, B, A], compression=1, noop=3)))
+    cases.append(("psd_1ch_raw", psd([R])))
+    cases.append(("psd_2ch_rle", psd([R, G], compression=1)))
+    cases.append(("psd_5ch_raw", psd([R, G, B, A, G])))
+    cases.append(("psd_5ch_rle", psd([R, G, B, A, B], compression=1)))
+    cases.append(("psd_blocks", psd([R, G, B], blocks=(b"\x01\x02\x03\x04\x05", bytes(range(37)), b"\xff" * 12))))
+    cases.append(("psd_truncated_raw", psd([R, G, B])[:-(W * H + 40)]))                 # past the end every byte reads 0
+    cases.append(("psd_rle_depth16", psd([R, G, B], depth=16, compression=1)))           # RLE is read as bytes whatever the depth says
+    cases.append(("psd_0ch", psd([], channels=0)))
+    # refused by stb_image
+    cases.append(("fail_psd_cmyk", psd([R, G, B, A], mode=4)))
+    cases.append(("fail_psd_grey", psd([R], mode=1)))
+    cases.append(("fail_psd_version2", psd([R, G, B], version=2)))
+    cases.append(("fail_psd_zip", psd([R, G, B], compression=2)))
+    cases.append(("fail_psd_depth32", psd([R, G, B], depth=32)))
+    cases.append(("fail_psd_17ch", psd([R, G, B], channels=17)))
+    cases.append(("fail_psd_bad_rle", psd([R, G, B], compression=1, raw_tail=b"\x00" * (H * 3 * 2) + bytes([257 - 120, 7]) * 3)))   # 360 > 253 pixels
+
+    def pic(packets, rows, w=W, h=H, magic=b"\x53\x80\xf6\x34", tag=b"PICT"):
+        """packets: [(size, type, channelmask)], rows: per scanline the concatenated packet data"""
+        hd = magic + struct.pack(">f", 3.71) + b"golden vector".ljust(80, b"\0") + tag + struct.pack(">HHfHH", w, h, 1.0, 3, 0)
+        for i, (size, typ, mask) in enumerate(packets):
+            hd += bytes([1 if i + 1 < len(packets) else 0, size, typ, mask])
+        return hd + b"".join(rows)
+
+    def raw_vals(y, chans): return rgba[y][:, chans].tobytes()
+
+    def mixed(y, chans, w=W, src=None):
+        src = rgba if src is None else src
+        out = bytearray(); x = 0
+        while x < w:
+            j = x
+            while j + 1 < w and np.array_equal(src[y, j + 1, chans], src[y, x, chans]) and j - x < 127: j += 1
+            if j > x:
+                out += bytes([127 + (j - x + 1)]) + src[y, x, chans].tobytes(); x = j + 1
+            else:
+                j = x
+                while j + 1 < w and not np.array_equal(src[y, j + 1, chans], src[y, j, chans]) and j - x < 127: j += 1
+                out += bytes([j - x]) + src[y, x:j + 1][:, chans].tobytes(); x = j + 1
+        return bytes(out)
+
+    def pure(y, chans, clamp=False):
+        out = bytearray(); x = 0
+        while x < W:
+            j = x
+            while j + 1 < W and np.array_equal(rgba[y, j + 1, chans], rgba[y, x, chans]) and j - x < 254: j += 1
+            n = j - x + 1
+            out += bytes([min(255, n + 9) if clamp and j + 1 == W else n]) + rgba[y, x, chans].tobytes(); x = j + 1
+        return bytes(out)
+    RGB, ALL = [0, 1, 2], [0, 1, 2, 3]
+    cases.append(("pic_rgb_raw", pic([(8, 0, 0xE0)], [raw_vals(y, RGB) for y in range(H)])))
+    cases.append(("pic_rgba_raw", pic([(8, 0, 0xF0)], [raw_vals(y, ALL) for y in range(H)])))
+    cases.append(("pic_rgb_mixed", pic([(8, 2, 0xE0)], [mixed(y, RGB) for y in range(H)])))
+    cases.append(("pic_rgb_mixed_alpha_pure", pic([(8, 2, 0xE0), (8, 1, 0x10)], [mixed(y, RGB) + pure(y, [3]) for y in range(H)])))
+    cases.append(("pic_pure_clamped", pic([(8, 1, 0xE0)], [pure(y, RGB, clamp=True) for y in range(H)])))
+    cases.append(("pic_r_raw_gb_mixed", pic([(8, 0, 0x80), (8, 2, 0x60)], [raw_vals(y, [0]) + mixed(y, [1, 2]) for y in range(H)])))
+    cases.append(("pic_alpha_only", pic([(8, 1, 0x10)], [pure(y, [3]) for y in range(H)])))
+    cases.append(("pic_red_twice", pic([(8, 0, 0xE0), (8, 2, 0x80)], [raw_vals(y, RGB) + mixed(y, [1]) for y in range(H)])))     # a later packet overwrites
+    wide_img = np.zeros((3, 300, 4), np.uint8); wide_img[..., 0] = 9; wide_img[1, 150:, 0] = 200; wide_img[..., 1] = (np.arange(300) // 100 * 60)[None, :]; wide_img[..., 2] = 33
+    long_rows = []
+    for y in range(3):
+        row = bytearray(); x = 0
+        while x < 300:
+            j = x
+            while j + 1 < 300 and np.array_equal(wide_img[y, j + 1, :3], wide_img[y, x, :3]): j += 1
+            n = j - x + 1
+            row += (bytes([128]) + struct.pack(">H", n) if n > 128 else bytes([127 + n]) if n > 1 else bytes([0])) + wide_img[y, x, :3].tobytes(); x = j + 1
+        long_rows.append(bytes(row))
+    cases.append(("pic_mixed_long_runs", pic([(8, 2, 0xE0)], long_rows, w=300, h=3)))
+    # refused by stb_image
+    cases.append(("fail_pic_16bit_packet", pic([(16, 0, 0xE0)], [raw_vals(y, RGB) for y in range(H)])))
+    cases.append(("fail_pic_type3", pic([(8, 3, 0xE0)], [raw_vals(y, RGB) for y in range(H)])))
+    cases.append(("fail_pic_overrun", pic([(8, 2, 0xE0)], [bytes([127 + 30, 1, 2, 3])] * H)))               # a run of 30 in a row of 23
+    cases.append(("fail_pic_truncated", pic([(8, 0, 0xE0)], [raw_vals(y, RGB) for y in range(H)])[:-50]))
+    cases.append(("fail_pic_11_packets", pic([(8, 0, 0x80)] * 11, [raw_vals(y, [0]) * 11 for y in range(H)])))
+    out = {}; names = []
+    for name, data in cases:
+        assert len(data) % 128 != 0, name           # (stb's end-of-file test depends on its 128-byte read buffer exactly there)
+        p = os.path.join(tmp, name)
+        with open(p, "wb") as f:
+            f.write(data)
+        w = C.c_int(); h = C.c_int()
+        ok = ref.lib.ref_image_load(p.encode(), C.byref(w), C.byref(h))
+        assert (ok == 1) == (not name.startswith("fail_")), (name, ok)
+        out["file_" + name] = np.frombuffer(data, np.uint8)
+        if ok == 1:
+            px = np.zeros((h.value, w.value, 4), np.uint8)
+            ref.lib.ref_image_data(px.ctypes.data_as(C.POINTER(C.c_ubyte)))
+            out["rgba_" + name] = px
+        names.append(name)
+        print("  ", name, len(data), "bytes ->", (w.value, h.value) if ok == 1 else "refused")
+    save("tier_k_images_psd_pic.npz", names=np.array(names), **out)
+
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
 from resize_cases import RESIZE_CASES, resize_case_input   # noqa: E402  (shared with tests/test_host_cpu.py)
 
@@ -542,8 +687,12 @@ def tier_k_resize(ref: Ref, tmp: str):
 def main():
     ref = Ref()
     with tempfile.TemporaryDirectory() as tmp:
+        if len(sys.argv) > 1 and sys.argv[1] == "psd_pic":           # only the fixture added last (the others stay as committed)
+            tier_k_images_psd_pic(ref, tmp)
+            return
         tier_k(ref, tmp)
         tier_k_images(ref, tmp)
+        tier_k_images_psd_pic(ref, tmp)
         tier_k_resize(ref, tmp)
         tier_k_scene(ref, tmp)
         tier_t(ref, tmp)

@@ -2,7 +2,7 @@
 // on stb_image / stb_image_resize) with a small own decoder.  Off the per-sample path: images are
 // decoded once to RGBA8 and uploaded into the device texel atlas by PathTracer::BuildBVH.
 //
-// Formats: BMP and TGA (every variant stb_image 2.27 accepts), GIF (first frame), Radiance HDR (reduced to 8 bits as stbi_load does), binary PNM (P5 / P6, maxval <= 255 or 16-bit), PNG incl. Adam7 interlace and colour-key tRNS (colour types 0, 2, 3, 4, 6;
+// Formats: BMP and TGA (every variant stb_image 2.27 accepts), GIF (first frame), Photoshop PSD (composite image) and Softimage PIC, Radiance HDR (reduced to 8 bits as stbi_load does), binary PNM (P5 / P6, maxval <= 255 or 16-bit), PNG incl. Adam7 interlace and colour-key tRNS (colour types 0, 2, 3, 4, 6;
 // bit depths 1-16) through zlib, and baseline / extended-sequential / progressive Huffman JPEG (grey, YCbCr, RGB, CMYK, YCCK).  Everything is expanded to 4 channels the way stbi_load(..., 4)
 // does (grey -> g,g,g,255; 16-bit -> high byte).  Images with a side > 1024 are reduced so the
 // longest side is 1024 (image.cpp:47-60) with stb_image_resize's default downsampling (Mitchell kernel,
@@ -1257,6 +1257,181 @@ bool decode_gif(const std::vector<unsigned char>& d, int& w, int& h, std::vector
     }
 }
 
+// ---- Photoshop PSD: the flattened composite image, as stbi_load(..., 4) of stb_image 2.27 reads it (stb_image.h:6002-6252): version 1,
+// RGB colour mode, 8 or 16 bits per channel (16 -> high byte), raw or PackBits data, planar channels R G B A (a missing
+// colour channel reads 0, a missing alpha 255, channels beyond the fourth are ignored), and with an alpha channel the
+// "white matte" is removed from partially transparent pixels in float arithmetic.  Bytes past the end of the file read as 0.
+// Returns 1 decoded, 0 not a PSD, -1 a PSD that stb_image refuses (no other decoder is tried then, as in stbi__load_main).
+int decode_psd(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgba)
+{
+    LeReader r(d);
+    auto be16 = [&]() { const int a = r.u8(); return (a << 8) | r.u8(); };
+    auto be32 = [&]() { const unsigned a = (unsigned)be16(); return (a << 16) | (unsigned)be16(); };
+    if (be32() != 0x38425053u) return 0;                               // "8BPS"
+    if (be16() != 1) return -1;
+    r.skip(6);
+    const int channels = be16();
+    if (channels > 16) return -1;
+    const int hh = (int)be32(), ww = (int)be32();
+    if (hh > (1 << 24) || ww > (1 << 24)) return -1;
+    const int depth = be16();
+    if (depth != 8 && depth != 16) return -1;
+    if (be16() != 3) return -1;                                        // colour mode: RGB only
+    for (int k = 0; k < 3; k++) r.skip((long)(int)be32());             // mode data, image resources, layer and mask information
+    const int compression = be16();
+    if (compression > 1) return -1;
+    if (ww <= 0 || hh <= 0 || (unsigned long long)ww * (unsigned long long)hh * 4ull > 0x7fffffffull) return -1;
+    const size_t pixels = (size_t)ww * (size_t)hh;
+    rgba.assign(pixels * 4, 0);
+    if (compression)
+    {
+        r.skip((long)hh * channels * 2);                               // the per-row byte counts
+        for (int c = 0; c < 4; c++)
+        {
+            unsigned char* p = rgba.data() + c;
+            if (c >= channels) { for (size_t i = 0; i < pixels; i++, p += 4) *p = c == 3 ? 255 : 0; continue; }
+            size_t count = 0;
+            while (count < pixels)
+            {
+                int len = r.u8();
+                const size_t left = pixels - count;
+                if (len == 128) continue;                              // no-op
+                if (len < 128)
+                {
+                    len++;
+                    if ((size_t)len > left) return -1;
+                    count += (size_t)len;
+                    for (; len; len--, p += 4) *p = (unsigned char)r.u8();
+                }
+                else
+                {
+                    len = 257 - len;
+                    if ((size_t)len > left) return -1;
+                    const unsigned char v = (unsigned char)r.u8();
+                    count += (size_t)len;
+                    for (; len; len--, p += 4) *p = v;
+                }
+            }
+        }
+    }
+    else
+    {
+        for (int c = 0; c < 4; c++)
+        {
+            unsigned char* p = rgba.data() + c;
+            if (c >= channels) { for (size_t i = 0; i < pixels; i++, p += 4) *p = c == 3 ? 255 : 0; }
+            else if (depth == 16) { for (size_t i = 0; i < pixels; i++, p += 4) *p = (unsigned char)(be16() >> 8); }
+            else { for (size_t i = 0; i < pixels; i++, p += 4) *p = (unsigned char)r.u8(); }
+        }
+    }
+    if (channels >= 4)
+        for (size_t i = 0; i < pixels; i++)
+        {
+            unsigned char* px = rgba.data() + 4 * i;
+            if (px[3] != 0 && px[3] != 255)
+            {
+                const float a = px[3] / 255.0f;
+                const float ra = 1.0f / a;
+                const float inv_a = 255.0f * (1 - ra);
+                for (int k = 0; k < 3; k++) px[k] = (unsigned char)(int)(px[k] * ra + inv_a);     // (as the reference's build converts: through int, low byte)
+            }
+        }
+    w = ww; h = hh;
+    return 1;
+}
+
+// ---- Softimage PIC, as stb_image 2.27 reads it (stb_image.h:6256-6470): 8-bit channels delivered by up to ten chained
+// packets per scanline (uncompressed, pure run-length or mixed run-length), channels a packet does not carry keep 0xff.
+// Returns 1 decoded, 0 not a PIC, -1 a PIC that stb_image refuses.
+int decode_pic(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgba)
+{
+    LeReader r(d);
+    auto be16 = [&]() { const int a = r.u8(); return (a << 8) | r.u8(); };
+    auto at_eof = [&]() { return r.pos >= r.n; };
+    static const unsigned char magic[4] = { 0x53, 0x80, 0xF6, 0x34 };
+    for (int i = 0; i < 4; i++) if (r.u8() != magic[i]) return 0;
+    for (int i = 0; i < 84; i++) (void)r.u8();
+    if (r.u8() != 'P' || r.u8() != 'I' || r.u8() != 'C' || r.u8() != 'T') return 0;
+    const int ww = be16(), hh = be16();
+    if (at_eof()) return -1;
+    r.skip(8);                                                         // ratio, fields, pad
+    if (ww <= 0 || hh <= 0) return -1;
+    rgba.assign((size_t)ww * hh * 4, 0xff);
+    struct Packet { int type, channel; } packets[10];
+    int num_packets = 0, chained;
+    do
+    {
+        if (num_packets == 10) return -1;
+        chained = r.u8();
+        const int size = r.u8();
+        packets[num_packets].type = r.u8();
+        packets[num_packets].channel = r.u8();
+        num_packets++;
+        if (at_eof()) return -1;
+        if (size != 8) return -1;
+    } while (chained);
+    // the bytes of one value for the channels in `mask` (0x80 R, 0x40 G, 0x20 B, 0x10 A)
+    auto readval = [&](int mask, unsigned char* dest) {
+        for (int i = 0, bit = 0x80; i < 4; i++, bit >>= 1)
+            if (mask & bit) { if (at_eof()) return false; dest[i] = (unsigned char)r.u8(); }
+        return true;
+    };
+    auto copyval = [](int mask, unsigned char* dest, const unsigned char* src) {
+        for (int i = 0, bit = 0x80; i < 4; i++, bit >>= 1) if (mask & bit) dest[i] = src[i];
+    };
+    for (int y = 0; y < hh; y++)
+        for (int k = 0; k < num_packets; k++)
+        {
+            const Packet& pk = packets[k];
+            unsigned char* dest = rgba.data() + (size_t)y * ww * 4;
+            if (pk.type == 0)
+            {
+                for (int x = 0; x < ww; x++, dest += 4) if (!readval(pk.channel, dest)) return -1;
+            }
+            else if (pk.type == 1)
+            {
+                int left = ww;
+                while (left > 0)
+                {
+                    int count = r.u8();
+                    if (at_eof()) return -1;
+                    if (count > left) count = left & 0xff;            // (stb narrows `left` to a byte here)
+                    unsigned char value[4];
+                    if (!readval(pk.channel, value)) return -1;
+                    for (int i = 0; i < count; i++, dest += 4) copyval(pk.channel, dest, value);
+                    left -= count;
+                }
+            }
+            else if (pk.type == 2)
+            {
+                int left = ww;
+                while (left > 0)
+                {
+                    int count = r.u8();
+                    if (at_eof()) return -1;
+                    if (count >= 128)
+                    {
+                        count = count == 128 ? be16() : count - 127;
+                        if (count > left) return -1;
+                        unsigned char value[4];
+                        if (!readval(pk.channel, value)) return -1;
+                        for (int i = 0; i < count; i++, dest += 4) copyval(pk.channel, dest, value);
+                    }
+                    else
+                    {
+                        count++;
+                        if (count > left) return -1;
+                        for (int i = 0; i < count; i++, dest += 4) if (!readval(pk.channel, dest)) return -1;
+                    }
+                    left -= count;
+                }
+            }
+            else return -1;
+        }
+    w = ww; h = hh;
+    return 1;
+}
+
 // ---- Radiance HDR (.hdr), reduced to 8 bits the way stbi_load does (stb_image.h:7009-7209 + stbi__hdr_to_ldr :1864-1888):
 // RGBE -> float (mantissa * 2^(e-136)), then (float)pow(v, 1/2.2f) * 255 + 0.5 truncated, alpha 255.
 bool decode_hdr(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgba)
@@ -1671,9 +1846,12 @@ void Image::Load(const std::string& filename)
     std::vector<unsigned char> file, rgba;
     int w = 0, h = 0;
     if (!read_file(filename, file)) return;                       // missing file -> mData == 0 -> sampler returns 0
-    // probe order of stbi__load_main (stb_image.h:1125-1166): PNG, BMP, ... JPEG, PNM, and TGA last (weakest signature)
-    if (!decode_png(file, w, h, rgba) && !decode_bmp(file, w, h, rgba) && !decode_gif(file, w, h, rgba) && !decode_jpeg(file, w, h, rgba) &&
-        !decode_pnm(file, w, h, rgba) && !decode_hdr(file, w, h, rgba) && !decode_tga(file, w, h, rgba)) return;
+    // probe order of stbi__load_main (stb_image.h:1125-1166): PNG, BMP, GIF, PSD, PIC, JPEG, PNM, HDR, and TGA last (weakest signature)
+    bool ok = decode_png(file, w, h, rgba) || decode_bmp(file, w, h, rgba) || decode_gif(file, w, h, rgba);
+    if (!ok) { const int r = decode_psd(file, w, h, rgba); if (r < 0) return; ok = r > 0; }
+    if (!ok) { const int r = decode_pic(file, w, h, rgba); if (r < 0) return; ok = r > 0; }
+    if (!ok) ok = decode_jpeg(file, w, h, rgba) || decode_pnm(file, w, h, rgba) || decode_hdr(file, w, h, rgba) || decode_tga(file, w, h, rgba);
+    if (!ok) return;
     if (w > 1024 || h > 1024)
     {
         float scale = 1024.f / fmax(w, h);                        // image.cpp:49

@@ -257,6 +257,34 @@ def test_texture_decoders_match_stb_image(tmp_path):
         assert np.array_equal(got, z["rgba_" + name]), (name, int(np.abs(got.astype(int) - z["rgba_" + name].astype(int)).max()))
 
 
+def test_psd_and_pic_textures_decode_like_stb_image(tmp_path):
+    """The last two formats of stbi_load (Image::Load, image.cpp:38-61): Photoshop PSD - 8 / 16 bit, raw and PackBits with no-op
+    codes, 0-5 channels, the white-matte removal for partial alpha, a truncated file (zeros), blocks to skip - and Softimage PIC -
+    uncompressed, pure and mixed run-length packets, channels split over chained packets, 16-bit run lengths - decode to the
+    reference's RGBA8; and the files stb_image refuses (CMYK / grey / PSB / zip / 32 bit PSDs, bad run lengths, 16-bit or unknown
+    PIC packets, overruns, truncation) yield no texture here either (golden: oracle/gen_golden.py tier_k_images_psd_pic)."""
+    from pbrpathtracer_amd import pathtracer as P
+    z = load_golden("tier_k_images_psd_pic.npz")
+    names = [str(n) for n in z["names"]]
+    assert len(names) >= 35 and sum(n.startswith("fail_") for n in names) >= 12
+    for name in names:
+        p = str(tmp_path / (name + (".psd" if "psd" in name else ".pic")))
+        open(p, "wb").write(z["file_" + name].tobytes())
+        got = P.image_load(p)
+        if name.startswith("fail_"):
+            assert got is None, name
+            continue
+        assert got is not None, name
+        want = z["rgba_" + name]
+        assert got.shape == want.shape, name
+        assert np.array_equal(got, want), (name, int(np.abs(got.astype(int) - want.astype(int)).max()))
+    # the generator's own inputs, so that the fixture is known to hold real images and not noise stb happened to accept
+    a = z["rgba_psd_rgba8_raw_matte"]; b = z["rgba_pic_rgba_raw"]
+    assert np.array_equal(a[..., 3], b[..., 3]) and np.array_equal(z["rgba_psd_rgb8_raw"][..., :3], b[..., :3])
+    assert np.array_equal(z["rgba_psd_rgb8_rle"], z["rgba_psd_rgb8_raw"]) and np.array_equal(z["rgba_pic_rgb_mixed"], z["rgba_pic_rgb_raw"])
+    assert (z["rgba_psd_rgba8_raw_matte"][..., :3] != z["rgba_psd_rgb8_raw"][..., :3]).any()        # the matte removal did something
+
+
 def _write_png(path, a):
     """Minimal PNG writer (8-bit grey / RGB / RGBA, filter 0) so the test needs no imaging library."""
     import struct
