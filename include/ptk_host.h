@@ -38,6 +38,7 @@ void pth_set_resolution(pth_tracer* t, int w, int h);
 void pth_get_resolution(pth_tracer* t, int* w, int* h);
 int  pth_num_objects(pth_tracer* t);
 int  pth_num_elements(pth_tracer* t, int obj);
+int  pth_name(pth_tracer* t, int obj, int elem, char* out, int cap);   /* name of object `obj` (elem < 0) or of its element; returns its length, -1 if there is none */
 void pth_set_camera(pth_tracer* t, const float pos[3], const float dir[3], const float up[3]);
 void pth_set_projection(pth_tracer* t, float f, float fovy);
 void pth_set_focal_dist(pth_tracer* t, float d);

@@ -516,6 +516,69 @@ def tier_k_images(ref: Ref, tmp: str):
     save("tier_k_images.npz", names=np.array(names), **out)
 
 
+OBJ_VARIANTS = {
+    # name: OBJ text.  What PathTracer::LoadObject (pathtracer.cpp:41-145) stages from files the way exporters really write them.
+    # (Not covered, because the reference itself reads out of bounds there: faces that omit vt / vn while the file has such lines.)
+    "tri_v_vt_vn": "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nvn 0 0 1\nf 1/1/1 2/2/1 3/3/1\n",
+    "quads_and_pentagon": "o box\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 1.5 0\nv 2 0 0.3\nv 2 1 -0.2\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvt 0.5 1\nvn 0 0 1\nvn 0 1 0\n"
+                          "f 1/1/1 2/2/1 3/3/1 4/4/1\nf 4/4/1 3/3/1 5/5/2\nf 1/1/1 2/2/1 3/3/1 5/5/2 4/4/1\nf 2/2/2 6/1/2 7/3/2 3/4/2\n",
+    "concave_polygons": "v 0 0 0\nv 2 0 0\nv 2 2 0\nv 1 0.5 0\nv 0 2 0\nv 3 0 0\nv 4 0 1\nv 4 2 0\nv 3.2 0.4 0.5\nvn 0 0 1\nvt 0 0\n"
+                        "f 1/1/1 2/1/1 3/1/1 4/1/1 5/1/1\nf 6/1/1 7/1/1 8/1/1 9/1/1\n",
+    "negative_indices": "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nvn 0 0 1\nf -3/-3/-1 -2/-2/-1 -1/-1/-1\nv 0 0 1\nv 1 0 1\nv 0 1 1\nvt 0.5 0.5\nvn 1 0 0\nf -3/-1/-1 -2/-4/-2 -1/1/1\n",
+    "positions_only": "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0.5\nf 1 2 3\nf 2 4 3\nf 1 2 4 3\n",
+    "v_and_vn_only": "v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 2\nvn 0.3 0.1 0.9\nf 1//1 2//2 3//1\n",
+    "v_and_vt_only": "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0.25 0.75\nvt 1.5 -0.5 0\nvt 0 1 0.3\nf 1/1 2/2 3/3\n",
+    "groups_objects": "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nv 0 0 1\nf 1 2 3\no first\nf 2 4 3\ng second group\nf 1 2 5\ng\nf 1 3 5\ng empty\ng third\no fourth\ng fifth\nf 2 3 5\nf 3 4 5\n",
+    "smoothing_groups": "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nv 0 0 1\nvn 0 0 1\nvn 0 1 0\nf 1//1 2//1 3//2\ns 1\nf 2//1 4//1 3//2\ns off\nf 1//1 2//1 5//2\ns 0\nf 1//1 3//1 5//2\ns 7\ng next\nf 2//1 3//1 5//2\ns  2 \nf 3//2 4//2 5//1\n",
+    "crlf_tabs_comments": "# a comment\r\n\r\nv\t0 0 0\r\nv 1  0\t0  \r\nv 0 1 0\r\n  v 1 1 0\r\n# f 1 2 3\r\nvn 0 0 1\r\n\tf 1//1 2//1 3//1   \r\nf 2//1\t4//1 3//1\r\n",
+    "colours_and_extras": "mtllib nowhere.mtl\nv 0 0 0 1 0 0\nv 1 0 0 0 1 0\nv 0 1 0 0 0 1\nv 1 1 0\nvt 0.1 0.2 0.3\nvn 0 0 1\nusemtl red\nf 1/1/1 2/1/1 3/1/1\nusemtl blue\nf 2/1/1 4/1/1 3/1/1\nl 1 2\np 1\n",
+    "number_forms": "v 1e-1 +.5 -0.\nv 1.5E+0 2.e-1 .25\nv -1.25e1 3 4.0000001\nv 00012 0.1e1 1e0\nvn 0 0 1e0\nvt 5.e-1 1E-1\nf 1/1/1 2/1/1 3/1/1\nf 2/1/1 4/1/1 3/1/1\n",
+    "no_trailing_newline": "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3",
+    "no_faces": "v 0 0 0\nv 1 0 0\nv 0 1 0\ng nothing\n",
+    "usemtl_then_group": "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nusemtl a\ng one\nf 1 2 3\nusemtl b\nf 2 4 3\ng two\nusemtl a\nf 1 2 4\n",
+    # polygons: a convex hexagon in the XZ plane, an L-shaped octagon in YZ, a star (non-planar), collinear runs, a square (equal diagonals), a
+    # bent quad, an all-collinear "polygon" (ear clipping gives up), a two-corner face between triangles
+    "polygons_axes": "v 1 0 0\nv 0.5 0 0.87\nv -0.5 0 0.87\nv -1 0 0\nv -0.5 0 -0.87\nv 0.5 0 -0.87\n"
+                     "v 3 0 0\nv 3 2 0\nv 3 2 1\nv 3 1 1\nv 3 1 3\nv 3 0 3\nv 3 0 2\nv 3 0 1\n"
+                     "f 1 2 3 4 5 6\nf 7 8 9 10 11 12 13 14\nf 6 5 4 3 2 1\n",
+    "polygons_star_and_degenerate": "v 0 3 0\nv 0.7 1 0.1\nv 3 1 0\nv 1.2 -0.3 -0.1\nv 2 -3 0\nv 0 -1.2 0.2\nv -2 -3 0\nv -1.2 -0.3 0\nv -3 1 0\nv -0.7 1 0\n"
+                                    "v 5 0 0\nv 6 0 0\nv 7 0 0\nv 8 0 0\nv 9 0 0\n"
+                                    "v 0 0 5\nv 1 0 5\nv 1 1 5\nv 0 1 5\nv 2 0 5.5\nv 2 1 4.5\n"
+                                    "f 1 2 3 4 5 6 7 8 9 10\nf 11 12 13 14 15\nf 16 17 18 19\nf 17 20 21 18\nf 1 2\nf 16 17 18\nf 11 12 13 3 14\n",
+    "statements_edge_cases": "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nv 0 0 1\ng   two   names\there \ns 3\nf 1 2 3\ns\nf 2 4 3\ns \nf 1 2 5\no  spaced name  \nf 1 3 5\ng \nf 2 3 5\no\nf 3 4 5\ngroup 7\nf 1 4 5\n",
+}
+
+
+def tier_k_obj_variants(ref: Ref, tmp: str):
+    """PathTracer::LoadObject (pathtracer.cpp:41-145 = tinyobj::LoadObj 2.0.0, triangulating) on OBJ files of every common
+    flavour: the staged triangles in file order (positions, normals, uvs, smoothing flag, element id) and the element count."""
+    M = np.zeros(16, np.float32)
+    ref.lib.ref_trs_matrix(_fp(np.array((0.1, -0.2, 0.3), np.float32)), _fp(np.array((10.0, 20.0, -5.0), np.float32)),
+                           _fp(np.array((1.0, 2.0, 0.5), np.float32)), _fp(M))
+    out = {}; names = []
+    for name, text in OBJ_VARIANTS.items():
+        p = os.path.join(tmp, name + ".obj")
+        with open(p, "wb") as f:
+            f.write(text.encode())
+        ref.lib.ref_clear()
+        ref.lib.ref_load_obj(p.encode(), _fp(M))
+        nobj = ref.lib.ref_num_objects()
+        nel = ref.lib.ref_num_elements(0) if nobj else -1
+        t = ref.triangles()
+        out["obj_" + name] = np.frombuffer(text.encode(), np.uint8)
+        out["tris_" + name] = t
+        out["elements_" + name] = np.int32(nel)
+        buf = C.create_string_buffer(256)
+        labels = []
+        for e in range(-1, max(nel, 0)):
+            if nobj: ref.lib.ref_name(0, e, buf, 256); labels.append(buf.value.decode("latin-1"))
+        out["labels_" + name] = np.array(labels if labels else [""], dtype="U64")          # object name, then the elements'
+        names.append(name)
+        print("  ", name, "objects", nobj, "elements", nel, "triangles", len(t), "element ids", sorted(set(t[:, 35].astype(int))) if len(t) else [])
+    ref.lib.ref_clear()
+    save("tier_k_obj_variants.npz", names=np.array(names), model=M, **out)
+
+
 def tier_k_images_psd_pic(ref: Ref, tmp: str):
     """Texture ingest, the two remaining stb_image formats: Photoshop PSD (composite image; stb_image.h:6002-6252) and Softimage
     PIC (:6256-6470).  No imaging library writes these: the files are assembled here byte by byte from the format descriptions;
@@ -687,12 +750,13 @@ def tier_k_resize(ref: Ref, tmp: str):
 def main():
     ref = Ref()
     with tempfile.TemporaryDirectory() as tmp:
-        if len(sys.argv) > 1 and sys.argv[1] == "psd_pic":           # only the fixture added last (the others stay as committed)
-            tier_k_images_psd_pic(ref, tmp)
+        if len(sys.argv) > 1 and sys.argv[1] in ("psd_pic", "obj_variants"):          # only one of the fixtures added last (the others stay as committed)
+            (tier_k_images_psd_pic if sys.argv[1] == "psd_pic" else tier_k_obj_variants)(ref, tmp)
             return
         tier_k(ref, tmp)
         tier_k_images(ref, tmp)
         tier_k_images_psd_pic(ref, tmp)
+        tier_k_obj_variants(ref, tmp)
         tier_k_resize(ref, tmp)
         tier_k_scene(ref, tmp)
         tier_t(ref, tmp)

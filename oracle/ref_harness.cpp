@@ -17,6 +17,7 @@
 //   by oracle/gen_golden.py to write the committed fixtures under tests/golden/.
 
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <cmath>
 #include <vector>
@@ -56,6 +57,15 @@ void ref_load_obj(const char* path, const float* model)
 
 int ref_num_objects() { return (int)g_pt.mLoadedObjects.size(); }
 int ref_num_elements(int obj) { return (int)g_pt.mLoadedObjects[obj].elements.size(); }
+// names of a loaded object (elem < 0) and of its elements as LoadObject (pathtracer.cpp:49-62) took them from tinyobj's shapes
+int ref_name(int obj, int elem, char* out, int cap)
+{
+    const std::string& n = elem < 0 ? g_pt.mLoadedObjects[obj].name : g_pt.mLoadedObjects[obj].elements[elem].name;
+    const int len = (int)std::min<size_t>(n.size(), (size_t)std::max(cap - 1, 0));
+    std::memcpy(out, n.data(), (size_t)len);
+    if (cap > 0) out[len] = 0;
+    return (int)n.size();
+}
 
 // m: type, diffuse rgb, specular rgb, emissive rgb, emissiveIntensity, roughness,
 //    reflectiveness, translucency, ior   (14 floats; type as 0/1)

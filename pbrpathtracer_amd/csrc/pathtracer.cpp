@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <limits>
 #include <sstream>
 #include <thread>
 
@@ -55,8 +56,10 @@ void triangle_init(StagedTriangle& t)
 
 // ---- Wavefront OBJ reader ------------------------------------------------------------------------------
 // Replaces tinyobj::LoadObj as used by PathTracer::LoadObject (pathtracer.cpp:43-47): v / vt / vn / f
-// (negative indices, v, v/vt, v//vn, v/vt/vn; polygons fan-triangulated), one shape per `o` or `g`
-// statement that is followed by faces (tiny_obj_loader.h:2820-2900), per-face smoothing group from `s`.
+// (negative indices, v, v/vt, v//vn, v/vt/vn; quads split along their shorter diagonal and larger polygons ear-clipped exactly as
+// tinyobj 2.0.0 triangulates them, tiny_obj_loader.h:1449-1856 - the reference's triangles ARE that triangulation), one shape
+// per `o` or `g` statement that is followed by faces (:2820-2900; a bare `g` / `o` without a blank behind it is no statement
+// there), per-face smoothing group from `s`.
 // Large files (a million triangles is 60 MB of text) are parsed by all cores: the file is cut at line ends into one chunk
 // per thread; a first pass counts the v / vn / vt statements of every chunk (relative face indices and the output offsets
 // need the counts before a line), a second parses numbers and faces in place; shapes and smoothing groups, which are
@@ -67,8 +70,10 @@ namespace {
 struct ObjFragment {
     bool new_shape = false;               // begins with an `o` / `g` statement
     std::string name;
-    std::vector<ObjIndex> indices;
-    std::vector<unsigned> smoothing;      // kUnknownSmoothing until the chunk's first `s`: the value flows in from before
+    std::vector<ObjIndex> indices;        // the faces' corners, concatenated
+    std::vector<unsigned> smoothing;      // per face; kUnknownSmoothing until the chunk's first `s`: the value flows in from before
+    std::vector<uint32_t> sizes;          // corners per face - only kept once a face is not a triangle (has_poly)
+    bool has_poly = false;
 };
 constexpr unsigned kUnknownSmoothing = 0xffffffffu;
 
@@ -180,18 +185,29 @@ void parse_chunk(ObjChunk& c, float* positions, float* normals, float* texcoords
                 }
                 face.push_back(ix);
             }
+            if (face.size() < 3) continue;                 // "degenerated face" (tiny_obj_loader.h:1449-1455)
             ObjFragment& f = c.frags.back();
-            for (size_t k = 2; k < face.size(); k++)
-            {
-                f.indices.push_back(face[0]); f.indices.push_back(face[k - 1]); f.indices.push_back(face[k]);
-                f.smoothing.push_back(s_known ? smoothing : kUnknownSmoothing);
-            }
+            if (face.size() != 3 && !f.has_poly) { f.has_poly = true; f.sizes.assign(f.smoothing.size(), 3u); }     // the first polygon of this fragment
+            if (f.has_poly) f.sizes.push_back((uint32_t)face.size());
+            f.indices.insert(f.indices.end(), face.begin(), face.end());
+            f.smoothing.push_back(s_known ? smoothing : kUnknownSmoothing);
         }
-        else if ((p[0] == 'o' || p[0] == 'g') && (c1 == ' ' || c1 == '\t' || c1 == '\0' || c1 == '\r'))
+        else if ((p[0] == 'o' || p[0] == 'g') && (c1 == ' ' || c1 == '\t'))
         {
-            const char* q = skip_blank(p + 1, e);
-            std::string name(q, e);
-            while (!name.empty() && (name.back() == '\r' || name.back() == ' ' || name.back() == '\t')) name.pop_back();
+            // (`g` alone on its line is not a group statement for tinyobj - it wants a blank behind the letter - and neither is `o`)
+            std::string name;
+            if (p[0] == 'o') { name.assign(p + 2, e); while (!name.empty() && name.back() == '\r') name.pop_back(); }     // the rest of the line as it stands (:2887-2890)
+            else
+            {
+                // the group's names joined by single blanks (:2841-2868)
+                for (const char* q = p + 1; q < e;)
+                {
+                    while (q < e && (*q == ' ' || *q == '\t' || *q == '\r')) q++;
+                    const char* w = q;
+                    while (q < e && *q != ' ' && *q != '\t' && *q != '\r') q++;
+                    if (q > w) { if (!name.empty()) name += ' '; name.append(w, q); }
+                }
+            }
             c.frags.emplace_back();
             c.frags.back().new_shape = true;
             c.frags.back().name = name;
@@ -199,11 +215,93 @@ void parse_chunk(ObjChunk& c, float* positions, float* normals, float* texcoords
         else if (p[0] == 's' && (c1 == ' ' || c1 == '\t'))
         {
             const char* q = skip_blank(p + 2, e);
+            if (q >= e || *q == '\r') continue;            // `s` without a value changes nothing (:2957-2963)
             if (e - q >= 3 && !std::strncmp(q, "off", 3)) smoothing = 0;
             else { int id = (int)std::strtol(q, nullptr, 10); smoothing = id < 0 ? 0u : (unsigned)id; }
             s_known = true; c.has_s = true; c.last_s = smoothing;
         }
     }
+}
+
+// tinyobj 2.0.0's triangulation of one face of four or more corners (tiny_obj_loader.h:1457-1856), in its float arithmetic
+// and with its quirks - the reference's triangle list is this function's output, so a fan would stage other triangles.
+void triangulate_face(const ObjIndex* face, size_t n, const float* v, size_t nv3, std::vector<ObjIndex>& out)
+{
+    auto valid = [&](int vi) { return 3 * (size_t)vi + 2 < nv3; };         // (a negative index wraps to a huge size_t, as there)
+    if (n == 4)
+    {
+        // the quad is cut along its shorter diagonal
+        if (!valid(face[0].v) || !valid(face[1].v) || !valid(face[2].v) || !valid(face[3].v)) return;
+        const float* a = v + 3 * (size_t)face[0].v; const float* b = v + 3 * (size_t)face[1].v;
+        const float* c = v + 3 * (size_t)face[2].v; const float* d = v + 3 * (size_t)face[3].v;
+        const float e02x = c[0] - a[0], e02y = c[1] - a[1], e02z = c[2] - a[2];
+        const float e13x = d[0] - b[0], e13y = d[1] - b[1], e13z = d[2] - b[2];
+        const float sqr02 = e02x * e02x + e02y * e02y + e02z * e02z;
+        const float sqr13 = e13x * e13x + e13y * e13y + e13z * e13z;
+        if (sqr02 < sqr13) { out.insert(out.end(), { face[0], face[1], face[2], face[0], face[2], face[3] }); }
+        else { out.insert(out.end(), { face[0], face[1], face[3], face[1], face[2], face[3] }); }
+        return;
+    }
+    // the two axes of the plane to work in: from the first corner that is not degenerate
+    size_t axes[2] = { 1, 2 };
+    for (size_t k = 0; k < n; k++)
+    {
+        const int i0 = face[k % n].v, i1 = face[(k + 1) % n].v, i2 = face[(k + 2) % n].v;
+        if (!valid(i0) || !valid(i1) || !valid(i2)) continue;
+        const float* p0 = v + 3 * (size_t)i0; const float* p1 = v + 3 * (size_t)i1; const float* p2 = v + 3 * (size_t)i2;
+        const float e0x = p1[0] - p0[0], e0y = p1[1] - p0[1], e0z = p1[2] - p0[2];
+        const float e1x = p2[0] - p1[0], e1y = p2[1] - p1[1], e1z = p2[2] - p1[2];
+        const float cx = std::fabs(e0y * e1z - e0z * e1y), cy = std::fabs(e0z * e1x - e0x * e1z), cz = std::fabs(e0x * e1y - e0y * e1x);
+        const float eps = std::numeric_limits<float>::epsilon();
+        if (cx > eps || cy > eps || cz > eps)
+        {
+            if (!(cx > cy && cx > cz))
+            {
+                axes[0] = 0;
+                if (cz > cx && cz > cy) axes[1] = 1;
+            }
+            break;
+        }
+    }
+    // ear clipping with a bounded number of fruitless rounds
+    std::vector<ObjIndex> rest(face, face + n);
+    size_t guess = 0, rounds_left = n, previous = n;
+    while (rest.size() > 3 && rounds_left > 0)
+    {
+        const size_t m = rest.size();
+        if (guess >= m) guess -= m;
+        if (previous != m) { previous = m; rounds_left = m; }
+        else rounds_left--;
+        ObjIndex ind[3]; float vx[3], vy[3];
+        for (size_t k = 0; k < 3; k++)
+        {
+            ind[k] = rest[(guess + k) % m];
+            const size_t vi = (size_t)ind[k].v;
+            if (vi * 3 + axes[0] >= nv3 || vi * 3 + axes[1] >= nv3) { vx[k] = 0.0f; vy[k] = 0.0f; }
+            else { vx[k] = v[vi * 3 + axes[0]]; vy[k] = v[vi * 3 + axes[1]]; }
+        }
+        const float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0], e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+        const float cross = e0x * e1y - e0y * e1x;
+        const float area = (vx[0] * vy[1] - vy[0] * vx[1]) * 0.5f;
+        if (cross * area < 0.0f) { guess += 1; continue; }                 // an internal angle
+        bool overlap = false;
+        for (size_t other = 3; other < m; other++)
+        {
+            const size_t idx = (guess + other) % m;
+            const size_t ovi = (size_t)rest[idx].v;
+            if (ovi * 3 + axes[0] >= nv3 || ovi * 3 + axes[1] >= nv3) continue;
+            const float tx = v[ovi * 3 + axes[0]], ty = v[ovi * 3 + axes[1]];
+            // point in triangle by crossing number (pnpoly, :1415-1427)
+            int inside = 0;
+            for (int i = 0, j = 2; i < 3; j = i++)
+                if (((vy[i] > ty) != (vy[j] > ty)) && (tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i])) inside = !inside;
+            if (inside) { overlap = true; break; }
+        }
+        if (overlap) { guess += 1; continue; }
+        out.insert(out.end(), { ind[0], ind[1], ind[2] });                // an ear
+        rest.erase(rest.begin() + (ptrdiff_t)((guess + 1) % m));
+    }
+    if (rest.size() == 3) out.insert(out.end(), { rest[0], rest[1], rest[2] });
 }
 
 }  // namespace
@@ -258,8 +356,24 @@ bool load_obj(const std::string& file, ObjData& out)
                 shape.name = f.name;
             }
             for (unsigned& sm : f.smoothing) { if (sm != kUnknownSmoothing) break; sm = smoothing; }
-            shape.indices.insert(shape.indices.end(), f.indices.begin(), f.indices.end());
-            shape.smoothing.insert(shape.smoothing.end(), f.smoothing.begin(), f.smoothing.end());
+            if (!f.has_poly)
+            {
+                shape.indices.insert(shape.indices.end(), f.indices.begin(), f.indices.end());
+                shape.smoothing.insert(shape.smoothing.end(), f.smoothing.begin(), f.smoothing.end());
+            }
+            else
+            {
+                // polygons among the faces: triangulated now that every position is known
+                size_t at = 0;
+                for (size_t k = 0; k < f.sizes.size(); k++)
+                {
+                    const size_t before = shape.indices.size();
+                    if (f.sizes[k] == 3) shape.indices.insert(shape.indices.end(), f.indices.begin() + (ptrdiff_t)at, f.indices.begin() + (ptrdiff_t)at + 3);
+                    else triangulate_face(f.indices.data() + at, f.sizes[k], out.positions.data(), out.positions.size(), shape.indices);
+                    shape.smoothing.insert(shape.smoothing.end(), (shape.indices.size() - before) / 3, f.smoothing[k]);
+                    at += f.sizes[k];
+                }
+            }
         }
         if (c.has_s) smoothing = c.last_s;
     }

@@ -1,6 +1,7 @@
 // C wrapper over the C++ host layer — see include/ptk_host.h.
 #include "ptk_host.h"
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 
@@ -73,6 +74,16 @@ int pth_num_elements(pth_tracer* t, int obj)
 {
     auto o = t->pt.GetLoadedObjects();
     return obj >= 0 && obj < (int)o.size() ? (int)o[obj].elements.size() : 0;
+}
+int pth_name(pth_tracer* t, int obj, int elem, char* out, int cap)
+{
+    const auto objs = t->pt.GetLoadedObjects();
+    if (obj < 0 || obj >= (int)objs.size() || elem >= (int)objs[obj].elements.size()) return -1;
+    const std::string& n = elem < 0 ? objs[obj].name : objs[obj].elements[elem].name;
+    const int len = (int)std::min<size_t>(n.size(), (size_t)std::max(cap - 1, 0));
+    std::memcpy(out, n.data(), (size_t)len);
+    if (cap > 0) out[len] = 0;
+    return (int)n.size();
 }
 void pth_set_camera(pth_tracer* t, const float* p, const float* d, const float* u)
 {

@@ -29,7 +29,7 @@ HOST_SYMBOLS = [
     "pth_create", "pth_destroy", "pth_load_object", "pth_set_material", "pth_set_texture", "pth_build_bvh",
     "pth_reset_image", "pth_clear_scene", "pth_get_samples", "pth_get_triangle_count", "pth_get_trace_depth",
     "pth_set_trace_depth", "pth_set_out_image", "pth_set_out_gl_buffer", "pth_set_out_device_image", "pth_set_resolution", "pth_get_resolution", "pth_num_objects",
-    "pth_num_elements", "pth_set_camera", "pth_set_projection", "pth_set_focal_dist", "pth_set_aperture",
+    "pth_num_elements", "pth_name", "pth_set_camera", "pth_set_projection", "pth_set_focal_dist", "pth_set_aperture",
     "pth_render_frame", "pth_exit", "pth_set_seed", "pth_set_tile", "pth_render_frames", "pth_read_accum",
     "pth_last_error", "pth_context", "pth_staged_scene", "pth_load_scene_file", "pth_pts_roundtrip",
     "pth_trs_matrix", "pth_euler_camera", "pth_triangle_init", "pth_image_load", "pth_image_data", "pth_image_tex2d",
@@ -55,6 +55,7 @@ def lib() -> C.CDLL:
     for n in ("pth_get_samples", "pth_get_triangle_count", "pth_get_trace_depth", "pth_num_objects"):
         getattr(L, n).restype = i32; getattr(L, n).argtypes = [vp]
     L.pth_num_elements.restype = i32; L.pth_num_elements.argtypes = [vp, i32]
+    L.pth_name.restype = i32; L.pth_name.argtypes = [vp, i32, i32, C.c_char_p, i32]
     L.pth_set_trace_depth.restype = None; L.pth_set_trace_depth.argtypes = [vp, i32]
     L.pth_set_out_image.restype = None; L.pth_set_out_image.argtypes = [vp, vp]
     L.pth_set_out_gl_buffer.restype = None; L.pth_set_out_gl_buffer.argtypes = [vp, C.c_uint]
@@ -193,6 +194,14 @@ class PathTracer:
         w = C.c_int(); h = C.c_int()
         self.L.pth_get_resolution(self.h, C.byref(w), C.byref(h))
         return w.value, h.value
+
+    def GetNames(self, obj: int):
+        """(object name, [element names]) of loaded object `obj` (PathTracerLoader::Object, pathtracer.cpp:49-62)."""
+        def one(e):
+            buf = C.create_string_buffer(1024)
+            n = self.L.pth_name(self.h, obj, e, buf, 1024)
+            return None if n < 0 else buf.value.decode("latin-1")
+        return one(-1), [one(e) for e in range(self.L.pth_num_elements(self.h, obj))]
 
     def GetLoadedObjects(self):
         return [self.L.pth_num_elements(self.h, i) for i in range(self.L.pth_num_objects(self.h))]

@@ -144,6 +144,38 @@ def test_load_object_staging_matches_reference(tmp_path):
     pt.close()
 
 
+def test_obj_files_of_every_flavour_stage_like_the_reference(tmp_path):
+    """PathTracer::LoadObject (pathtracer.cpp:41-145) = tinyobj::LoadObj 2.0.0 with triangulation, on OBJ files the way exporters
+    write them: quads (cut along the shorter diagonal), convex / concave / star-shaped / collinear / bent polygons (tinyobj's ear
+    clipping in its own projection plane, including the faces it gives up on), relative indices, v-only / v//vn / v/vt corners,
+    `o` and `g` statements in every order (bare `g`, empty groups, several names, faces before the first group, `usemtl` between),
+    smoothing groups (`s 1`, `s off`, `s` without a value), CRLF / tabs / comments / vertex colours / `l` and `p` statements /
+    exotic number forms / no trailing newline / no faces at all.  The staged triangles - positions, normals, uvs, tangent
+    frames, smoothing flags, element ids, IN FILE ORDER - the element count and the object and element names equal what the real
+    reference staged (golden: oracle/gen_golden.py tier_k_obj_variants)."""
+    from pbrpathtracer_amd.pathtracer import PathTracer
+    z = load_golden("tier_k_obj_variants.npz")
+    names = [str(n) for n in z["names"]]
+    assert len(names) >= 18
+    for name in names:
+        p = str(tmp_path / (name + ".obj"))
+        open(p, "wb").write(z["obj_" + name].tobytes())
+        pt = PathTracer()
+        pt.LoadObject(p, z["model"].reshape(4, 4))
+        t = z["tris_" + name]; nel = int(z["elements_" + name])
+        assert pt.GetLoadedObjects() == [nel], name
+        assert pt.GetTriangleCount() == len(t), (name, pt.GetTriangleCount(), len(t))
+        on, en = pt.GetNames(0)
+        assert [on] + en == [str(x) for x in z["labels_" + name]][:1 + nel], name
+        if len(t):
+            s_ = pt.StagedScene()
+            for k, (a, b) in dict(verts=(0, 9), normals=(9, 18), uvs=(18, 24), tbn=(24, 33)).items():
+                assert np.allclose(s_[k], t[:, a:b], rtol=0, atol=1e-6, equal_nan=True), (name, k)
+            assert np.array_equal(s_["smoothing"], (t[:, 33] != 0).astype(np.uint8)), name
+            assert np.array_equal(s_["material"], t[:, 35].astype(np.int32)), name
+        pt.close()
+
+
 def test_pts_reader_and_scene_push(tmp_path):
     from pbrpathtracer_amd import scenes as S
     from pbrpathtracer_amd.pathtracer import PathTracer, lib
@@ -182,7 +214,8 @@ def test_textured_scene_staging(tmp_path):
 
 def test_obj_reader_subset(tmp_path):
     """OBJ features the loader promises (tinyobj subset, pathtracer.cpp:41-145): quads and polygons
-    (fan-triangulated), negative indices, v//vn and v/vt forms, `g` groups as elements, smoothing groups,
+    (triangulated as tinyobj does: test_obj_files_of_every_flavour_stage_like_the_reference pins the triangles to the
+    reference's), negative indices, v//vn and v/vt forms, `g` groups as elements, smoothing groups,
     faces before any group, CRLF line ends."""
     from pbrpathtracer_amd.pathtracer import PathTracer
     obj = tmp_path / "m.obj"
@@ -207,10 +240,9 @@ def test_obj_reader_subset(tmp_path):
     assert list(s["smoothing"]) == [0, 1, 1, 0, 0, 0, 0]
     # x is negated on load (pathtracer.cpp:74), v flipped (pathtracer.cpp:88)
     assert np.allclose(s["verts"][0], [0, 0, 0, -1, 0, 0, -1, 1, 0])
-    assert np.allclose(s["uvs"][1], [0, 1, 1, 1, 1, 0])
+    # the unit square's diagonals are equally long: tinyobj then cuts (v1 v2 v4) (v2 v3 v4)
+    assert np.allclose(s["uvs"][1], [0, 1, 1, 1, 0, 0]) and np.allclose(s["uvs"][2], [1, 1, 1, 0, 0, 0])
     assert np.allclose(s["normals"][1][:3], [0, 0, 1])
-    # pentagon fan: (v1 v2 v3) (v1 v3 v4) (v1 v4 v5)
-    assert np.allclose(s["verts"][3][:3], [0, 0, 0]) and np.allclose(s["verts"][5][6:9], [0, 0, 1])
     pt.LoadObject(str(tmp_path / "does_not_exist.obj"))      # parse failure is silently ignored (:47)
     assert pt.GetLoadedObjects() == [4]
     pt.ClearScene()
