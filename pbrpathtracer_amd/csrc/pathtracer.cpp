@@ -467,7 +467,8 @@ void PathTracer::LoadObject(const std::string& file, const glm::mat4& model)
     if (nameStartIndex > (int)file.size() - 1) nameStartIndex = 0;
     size_t nameEnd = file.find_last_of(".");
     int nameEndIndex = nameEnd == std::string::npos ? (int)file.size() - 1 : (int)nameEnd;
-    std::string objName = nameEndIndex >= nameStartIndex ? file.substr(nameStartIndex, nameEndIndex - nameStartIndex) : std::string();
+    // (a dot that lies BEFORE the file name - "./mesh", "dir.v2/mesh" - makes the count negative: as a size_t it takes the rest, :56)
+    std::string objName = file.substr((size_t)nameStartIndex, (size_t)(nameEndIndex - nameStartIndex));
     PathTracerLoader::Object object(objName);
 
     const bool has_normals = !obj.normals.empty();

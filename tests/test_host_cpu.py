@@ -176,6 +176,22 @@ def test_obj_files_of_every_flavour_stage_like_the_reference(tmp_path):
         pt.close()
 
 
+def test_object_names_follow_the_reference_for_odd_paths(tmp_path, monkeypatch):
+    """LoadObject's object name (pathtracer.cpp:49-56): between the last '/' and the last '.', with the reference's quirks - no
+    extension loses the last character, a dot that lies before the file name ("./mesh", "dir.v2/mesh") gives the whole file name.
+    (Expected values taken from the reference itself with oracle/ref_harness.cpp's ref_name.)"""
+    from pbrpathtracer_amd.pathtracer import PathTracer
+    (tmp_path / "dir.with.dot").mkdir()
+    monkeypatch.chdir(tmp_path)
+    cases = {"plain.obj": "plain", "a.b.c.obj": "a.b.c", "noext": "noex", "./noext": "noext", "dir.with.dot/noext": "noext",
+             "dir.with.dot/x.obj": "x", ".hidden": "", "dir.with.dot/.obj": "", "trail.": "trail", "sp ace.obj": "sp ace", "back\\slash.obj": "back\\slash"}
+    for rel, want in cases.items():
+        open(rel, "w").write("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+        pt = PathTracer(); pt.LoadObject(rel)
+        assert pt.GetLoadedObjects() == [1] and pt.GetNames(0)[0] == want, (rel, pt.GetNames(0))
+        pt.close()
+
+
 def test_pts_reader_and_scene_push(tmp_path):
     from pbrpathtracer_amd import scenes as S
     from pbrpathtracer_amd.pathtracer import PathTracer, lib
