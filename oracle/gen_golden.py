@@ -516,6 +516,79 @@ def tier_k_images(ref: Ref, tmp: str):
     save("tier_k_images.npz", names=np.array(names), **out)
 
 
+def tier_k_images_jpeg_sampling(ref: Ref, tmp: str):
+    """Texture ingest: baseline JPEGs with the sampling factors no common encoder writes - 4:1:1, 4:4:0, 4:1:0, 3x1, mixed chroma
+    factors, a sub-sampled LUMA plane - through the generic MCU layout and the generic up-sampler (stb_image.h resample_row_generic).
+    The files come from a minimal encoder below: one DC coefficient per 8x8 block (all AC zero), quantiser 1, a flat 4-bit DC code
+    and a one-symbol AC code; the expected RGBA8 comes from the reference's stb_image."""
+    import struct
+    rng = np.random.default_rng(123)
+
+    def encode(w, h, factors, restart=0, seed=0):
+        r = np.random.default_rng(seed)
+        hmax = max(f[0] for f in factors); vmax = max(f[1] for f in factors)
+        mx = (w + 8 * hmax - 1) // (8 * hmax); my = (h + 8 * vmax - 1) // (8 * vmax)
+        out = bytearray(b"\xff\xd8")
+        out += b"\xff\xdb" + struct.pack(">HB", 67, 0) + bytes([1] * 64)
+        out += b"\xff\xc0" + struct.pack(">HBHHB", 8 + 3 * len(factors), 8, h, w, len(factors))
+        for i, (fh, fv) in enumerate(factors): out += bytes([i + 1, (fh << 4) | fv, 0])
+        out += b"\xff\xc4" + struct.pack(">HB", 19 + 12, 0x00) + bytes([0, 0, 0, 12] + [0] * 12) + bytes(range(12))     # DC: twelve 4-bit codes
+        out += b"\xff\xc4" + struct.pack(">HB", 19 + 1, 0x10) + bytes([1] + [0] * 15) + bytes([0])                     # AC: EOB = the code "0"
+        if restart: out += b"\xff\xdd" + struct.pack(">HH", 4, restart)
+        out += b"\xff\xda" + struct.pack(">HB", 6 + 2 * len(factors), len(factors))
+        for i in range(len(factors)): out += bytes([i + 1, 0x00])
+        out += bytes([0, 63, 0])
+        bits = []; pred = [0] * len(factors); count = 0; rst = 0
+
+        def flush():
+            nonlocal bits
+            while len(bits) % 8: bits.append(1)
+            for k in range(0, len(bits), 8):
+                b = int("".join(map(str, bits[k:k + 8])), 2); out.append(b)
+                if b == 0xff: out.append(0)
+            bits = []
+        for _ in range(mx * my):
+            for c, (fh, fv) in enumerate(factors):
+                for _b in range(fh * fv):
+                    dc = int(r.integers(-1000, 1000)) if r.uniform() < 0.8 else pred[c]
+                    d = dc - pred[c]; pred[c] = dc
+                    cat = 0 if d == 0 else int(abs(d)).bit_length()
+                    bits += [int(x) for x in format(cat, "04b")]
+                    if cat:
+                        v = d if d > 0 else d + (1 << cat) - 1
+                        bits += [int(x) for x in format(v, "0%db" % cat)]
+                    bits.append(0)                                  # EOB
+            count += 1
+            if restart and count % restart == 0 and count < mx * my:
+                flush(); out += bytes([0xff, 0xd0 + rst]); rst = (rst + 1) & 7; pred = [0] * len(factors)
+        flush()
+        out += b"\xff\xd9"
+        return bytes(out)
+    cases = [
+        ("jpg411", 70, 19, [(4, 1), (1, 1), (1, 1)]), ("jpg440", 21, 37, [(1, 2), (1, 1), (1, 1)]), ("jpg410", 67, 35, [(4, 2), (1, 1), (1, 1)]),
+        ("jpg_3x1", 50, 9, [(3, 1), (1, 1), (1, 1)]), ("jpg_1x4", 9, 70, [(1, 4), (1, 1), (1, 1)]), ("jpg_mixed_chroma", 33, 33, [(2, 2), (2, 1), (1, 2)]),
+        ("jpg_luma_subsampled", 40, 24, [(1, 1), (2, 2), (2, 2)]), ("jpg_4x4", 65, 65, [(4, 4), (1, 1), (2, 2)]), ("jpg_grey_2x2", 30, 20, [(2, 2)]),
+        ("jpg411_restart", 70, 19, [(4, 1), (1, 1), (1, 1)]), ("jpg_3x3_chroma3x1", 49, 27, [(3, 3), (3, 1), (1, 3)]),
+    ]
+    out = {}; names = []
+    for k, (name, w, h, factors) in enumerate(cases):
+        data = encode(w, h, factors, restart=2 if "restart" in name else 0, seed=k)
+        p = os.path.join(tmp, name + ".jpg")
+        with open(p, "wb") as f:
+            f.write(data)
+        ww = C.c_int(); hh = C.c_int()
+        ok = ref.lib.ref_image_load(p.encode(), C.byref(ww), C.byref(hh))
+        out["file_" + name] = np.frombuffer(data, np.uint8)
+        out["ok_" + name] = np.int32(ok)
+        if ok == 1:
+            px = np.zeros((hh.value, ww.value, 4), np.uint8)
+            ref.lib.ref_image_data(px.ctypes.data_as(C.POINTER(C.c_ubyte)))
+            out["rgba_" + name] = px
+        names.append(name)
+        print("  ", name, len(data), "bytes ->", (ww.value, hh.value, "distinct colours %d" % len(np.unique(px.reshape(-1, 4), axis=0))) if ok == 1 else "refused")
+    save("tier_k_images_jpeg_sampling.npz", names=np.array(names), **out)
+
+
 OBJ_VARIANTS = {
     # name: OBJ text.  What PathTracer::LoadObject (pathtracer.cpp:41-145) stages from files the way exporters really write them.
     # (Not covered, because the reference itself reads out of bounds there: faces that omit vt / vn while the file has such lines.)
@@ -750,12 +823,14 @@ def tier_k_resize(ref: Ref, tmp: str):
 def main():
     ref = Ref()
     with tempfile.TemporaryDirectory() as tmp:
-        if len(sys.argv) > 1 and sys.argv[1] in ("psd_pic", "obj_variants"):          # only one of the fixtures added last (the others stay as committed)
-            (tier_k_images_psd_pic if sys.argv[1] == "psd_pic" else tier_k_obj_variants)(ref, tmp)
+        only = {"psd_pic": tier_k_images_psd_pic, "obj_variants": tier_k_obj_variants, "jpeg_sampling": tier_k_images_jpeg_sampling}
+        if len(sys.argv) > 1 and sys.argv[1] in only:          # only one of the fixtures added last (the others stay as committed)
+            only[sys.argv[1]](ref, tmp)
             return
         tier_k(ref, tmp)
         tier_k_images(ref, tmp)
         tier_k_images_psd_pic(ref, tmp)
+        tier_k_images_jpeg_sampling(ref, tmp)
         tier_k_obj_variants(ref, tmp)
         tier_k_resize(ref, tmp)
         tier_k_scene(ref, tmp)

@@ -305,6 +305,24 @@ def test_texture_decoders_match_stb_image(tmp_path):
         assert np.array_equal(got, z["rgba_" + name]), (name, int(np.abs(got.astype(int) - z["rgba_" + name].astype(int)).max()))
 
 
+def test_jpegs_with_uncommon_sampling_factors_decode_like_stb_image(tmp_path):
+    """Baseline JPEGs whose sampling factors no common encoder writes - 4:1:1, 4:4:0, 4:1:0, 3x1, 1x4, 4x4, different factors for
+    Cb and Cr, a sub-sampled LUMA plane, a 2x2 grey image, restart markers - through the generic MCU layout and the generic
+    up-sampler: the reference's RGBA8 (golden: oracle/gen_golden.py tier_k_images_jpeg_sampling, files from its minimal encoder)."""
+    from pbrpathtracer_amd import pathtracer as P
+    z = load_golden("tier_k_images_jpeg_sampling.npz")
+    names = [str(n) for n in z["names"]]
+    assert len(names) >= 11
+    for name in names:
+        p = str(tmp_path / (name + ".jpg"))
+        open(p, "wb").write(z["file_" + name].tobytes())
+        got = P.image_load(p)
+        assert int(z["ok_" + name]) == 1 and got is not None, name
+        want = z["rgba_" + name]
+        assert got.shape == want.shape and np.array_equal(got, want), name
+        assert len(np.unique(want.reshape(-1, 4), axis=0)) > 8, name          # (a real picture, not a flat field)
+
+
 def test_psd_and_pic_textures_decode_like_stb_image(tmp_path):
     """The last two formats of stbi_load (Image::Load, image.cpp:38-61): Photoshop PSD - 8 / 16 bit, raw and PackBits with no-op
     codes, 0-5 channels, the white-matte removal for partial alpha, a truncated file (zeros), blocks to skip - and Softimage PIC -
