@@ -618,6 +618,10 @@ OBJ_VARIANTS = {
                                     "v 5 0 0\nv 6 0 0\nv 7 0 0\nv 8 0 0\nv 9 0 0\n"
                                     "v 0 0 5\nv 1 0 5\nv 1 1 5\nv 0 1 5\nv 2 0 5.5\nv 2 1 4.5\n"
                                     "f 1 2 3 4 5 6 7 8 9 10\nf 11 12 13 14 15\nf 16 17 18 19\nf 17 20 21 18\nf 1 2\nf 16 17 18\nf 11 12 13 3 14\n",
+    # which shapes survive (a shape is an element): `g` keeps the one before it only with triangles, `o` also with lines or points, the end
+    # of the file with any f / l / p statement - even a polygon the ear clipper gives up on or a two-corner face
+    "lines_points_shapes": "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nv 2 0 0\nv 3 0 0\nv 4 0 0\no wire\nl 1 2 3\no solid\nf 1 2 3\ng loose_lines\nl 2 3\ng pts\np 1 2\no after_points\nf 2 4 3\no only_degenerate\nf 1 2\ng tail\nf 1 5 6 7 5\n",
+    "ends_with_lines": "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\ng edges\nl 1 2\n",
     "statements_edge_cases": "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nv 0 0 1\ng   two   names\there \ns 3\nf 1 2 3\ns\nf 2 4 3\ns \nf 1 2 5\no  spaced name  \nf 1 3 5\ng \nf 2 3 5\no\nf 3 4 5\ngroup 7\nf 1 4 5\n",
 }
 

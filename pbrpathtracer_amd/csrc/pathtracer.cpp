@@ -74,6 +74,8 @@ struct ObjFragment {
     std::vector<unsigned> smoothing;      // per face; kUnknownSmoothing until the chunk's first `s`: the value flows in from before
     std::vector<uint32_t> sizes;          // corners per face - only kept once a face is not a triangle (has_poly)
     bool has_poly = false;
+    char kind = 0;                        // 'g' / 'o': which statement began it (they keep an empty shape by different rules, see load_obj)
+    bool any_f = false, any_l = false, any_p = false;     // `f` (of any corner count), `l`, `p` statements in it
 };
 constexpr unsigned kUnknownSmoothing = 0xffffffffu;
 
@@ -185,8 +187,9 @@ void parse_chunk(ObjChunk& c, float* positions, float* normals, float* texcoords
                 }
                 face.push_back(ix);
             }
-            if (face.size() < 3) continue;                 // "degenerated face" (tiny_obj_loader.h:1449-1455)
             ObjFragment& f = c.frags.back();
+            f.any_f = true;
+            if (face.size() < 3) continue;                 // "degenerated face" (tiny_obj_loader.h:1449-1455)
             if (face.size() != 3 && !f.has_poly) { f.has_poly = true; f.sizes.assign(f.smoothing.size(), 3u); }     // the first polygon of this fragment
             if (f.has_poly) f.sizes.push_back((uint32_t)face.size());
             f.indices.insert(f.indices.end(), face.begin(), face.end());
@@ -210,7 +213,12 @@ void parse_chunk(ObjChunk& c, float* positions, float* normals, float* texcoords
             }
             c.frags.emplace_back();
             c.frags.back().new_shape = true;
+            c.frags.back().kind = p[0];
             c.frags.back().name = name;
+        }
+        else if ((p[0] == 'l' || p[0] == 'p') && (c1 == ' ' || c1 == '\t'))
+        {
+            (p[0] == 'l' ? c.frags.back().any_l : c.frags.back().any_p) = true;       // lines / points: nothing to stage, but they keep a shape alive
         }
         else if (p[0] == 's' && (c1 == ' ' || c1 == '\t'))
         {
@@ -342,19 +350,26 @@ bool load_obj(const std::string& file, ObjData& out)
     for (ObjChunk& c : chunks) { c.v0 = nv; c.vn0 = nvn; c.vt0 = nvt; nv += c.nv; nvn += c.nvn; nvt += c.nvt; }
     out.positions.resize(nv * 3); out.normals.resize(nvn * 3); out.texcoords.resize(nvt * 2);
     parallel_for(nchunks, [&](size_t k) { parse_chunk(chunks[k], out.positions.data(), out.normals.data(), out.texcoords.data()); });
-    // stitch: shapes begin at `o` / `g` statements that are followed by faces; the smoothing group carries across chunks
+    // stitch: shapes begin at `o` / `g` statements; the smoothing group carries across chunks.  Which shapes survive follows
+    // tinyobj to the letter, because a shape is an ELEMENT and element numbers are what materials are set by: a `g` statement
+    // keeps the shape before it only if it has triangles (tiny_obj_loader.h:2826-2828), an `o` statement also if it has lines
+    // or points (:2880-2883), and the end of the file keeps the last shape if it saw ANY `f` / `l` / `p` statement, even when
+    // no triangle came of it - corners < 3, or a polygon the ear clipper gave up on (:3015-3022).
     ObjShape shape;
     unsigned smoothing = 0;
+    bool had_f = false, had_l = false, had_p = false;
     for (ObjChunk& c : chunks)
     {
         for (ObjFragment& f : c.frags)
         {
             if (f.new_shape)
             {
-                if (!shape.indices.empty()) out.shapes.push_back(std::move(shape));
+                if (!shape.indices.empty() || (f.kind == 'o' && (had_l || had_p))) out.shapes.push_back(std::move(shape));
                 shape = ObjShape();
                 shape.name = f.name;
+                had_f = had_l = had_p = false;
             }
+            had_f |= f.any_f; had_l |= f.any_l; had_p |= f.any_p;
             for (unsigned& sm : f.smoothing) { if (sm != kUnknownSmoothing) break; sm = smoothing; }
             if (!f.has_poly)
             {
@@ -377,7 +392,7 @@ bool load_obj(const std::string& file, ObjData& out)
         }
         if (c.has_s) smoothing = c.last_s;
     }
-    if (!shape.indices.empty()) out.shapes.push_back(std::move(shape));
+    if (!shape.indices.empty() || had_f || had_l || had_p) out.shapes.push_back(std::move(shape));
     return true;
 }
 
