@@ -62,9 +62,13 @@ bool decode_pnm(const std::vector<unsigned char>& d, int& w, int& h, std::vector
     pos++;   // single whitespace after maxval
     size_t bps = maxv > 255 ? 2 : 1;
     size_t need = (size_t)w * h * comp * bps;
-    if (pos + need > d.size()) return false;
-    rgba.resize((size_t)w * h * 4);
+    // (a file cut short still decodes in stb_image 2.27, which ignores the short read - the missing samples are whatever its
+    // buffer held; here they read 0)
+    if (pos > d.size() || (unsigned long long)w * (unsigned long long)h * 4ull > 0x7fffffffull) return false;
+    std::vector<unsigned char> padded;
     const unsigned char* p = d.data() + pos;
+    if (pos + need > d.size()) { padded.assign(need, 0); std::memcpy(padded.data(), p, d.size() - pos); p = padded.data(); }
+    rgba.resize((size_t)w * h * 4);
     for (size_t i = 0; i < (size_t)w * h; i++)
     {
         unsigned char c[3];
@@ -89,15 +93,16 @@ int paeth(int a, int b, int c)
 bool decode_png(const std::vector<unsigned char>& d, int& w, int& h, std::vector<unsigned char>& rgba)
 {
     static const unsigned char sig[8] = { 137, 80, 78, 71, 13, 10, 26, 10 };
-    if (d.size() < 33 || std::memcmp(d.data(), sig, 8) != 0) return false;
+    if (d.size() < 8 || std::memcmp(d.data(), sig, 8) != 0) return false;
     size_t pos = 8;
     int depth = 0, ctype = 0, interlace = 0;
     std::vector<unsigned char> idat, plte, trns;
-    bool have_ihdr = false;
-    while (pos + 12 <= d.size())
+    bool have_ihdr = false, saw_iend = false;
+    while (pos + 8 <= d.size())
     {
         uint32_t len = be32(&d[pos]);
         const unsigned char* type = &d[pos + 4];
+        if (!std::memcmp(type, "IEND", 4)) { saw_iend = true; break; }      // (its header is all stb_image waits for)
         if (pos + 12 + (size_t)len > d.size()) return false;
         const unsigned char* body = &d[pos + 8];
         if (!std::memcmp(type, "IHDR", 4))
@@ -110,9 +115,10 @@ bool decode_png(const std::vector<unsigned char>& d, int& w, int& h, std::vector
         else if (!std::memcmp(type, "PLTE", 4)) plte.assign(body, body + len);
         else if (!std::memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
         else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
-        else if (!std::memcmp(type, "IEND", 4)) break;
+        else if (!(type[0] & 0x20)) return false;          // a critical chunk stb_image does not know (stb_image.h "invalid_chunk")
         pos += 12 + (size_t)len;
     }
+    if (!saw_iend) return false;                           // cut short: stb_image reads zeros there, i.e. an invalid chunk, and gives up
     if (!have_ihdr || w <= 0 || h <= 0 || w > (1 << 15) || h > (1 << 15) || interlace > 1) return false;
     int channels;
     switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break;
@@ -702,7 +708,6 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
     m = next_marker();
     while (m != 0xd9)
     {
-        if (z.p >= z.end) break;
         if (m == 0xc0 || m == 0xc1 || m == 0xc2)                  // SOF0 / SOF1 / SOF2 (progressive)
         {
             z.progressive = m == 0xc2;
@@ -848,7 +853,17 @@ bool decode_jpeg(const std::vector<unsigned char>& d, int& w, int& h, std::vecto
             if (L < 2) return false;
             z.p += std::min<long>(L - 2, z.end - z.p);
         }
-        else if (m == 0xff) { /* fill bytes */ }
+        else if (m == 0xdc)                                        // DNL (stb_image.h stbi__decode_jpeg_image)
+        {
+            const int Ld = z.get16(), NL = z.get16();
+            if (Ld != 4 || NL != z.h || !have_frame) return false;
+        }
+        else if (m == 0xff)
+        {
+            // no marker where one is expected: before the frame header stb_image keeps looking, byte by byte, to the end of the
+            // file; behind it - a file cut short has no EOI - it gives up ("expected marker")
+            if (have_frame || z.p >= z.end) return false;
+        }
         else return false;
         m = next_marker();
     }
