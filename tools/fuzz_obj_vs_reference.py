@@ -51,7 +51,7 @@ for seed in range(first, first+count):
     ok = pt.GetLoadedObjects()==([nel] if nel>=0 else []) and pt.GetTriangleCount()==len(t)
     if ok and len(t):
         s=pt.StagedScene()
-        ok = np.array_equal(s['verts'],t[:,0:9]) and np.array_equal(s['normals'],t[:,9:18],equal_nan=True) and np.array_equal(s['uvs'],t[:,18:24]) and np.array_equal(s['smoothing'],(t[:,33]!=0).astype(np.uint8)) and np.array_equal(s['material'],t[:,35].astype(np.int32))
+        ok = np.array_equal(s['verts'],t[:,0:9]) and np.array_equal(s['normals'],t[:,9:18],equal_nan=True) and np.array_equal(s['uvs'],t[:,18:24]) and np.array_equal(s['tbn'].view(np.uint32),t[:,24:33].copy().view(np.uint32)) and np.array_equal(s['smoothing'],(t[:,33]!=0).astype(np.uint8)) and np.array_equal(s['material'],t[:,35].astype(np.int32))
     pt.close()
     if not ok:
         bad+=1; keep=os.path.join('/tmp',f'objfuzz_bad_{seed}.obj'); open(keep,'w').write(text); print("MISMATCH seed",seed,"mode",mode,"->",keep, "tris ref",len(t), flush=True)
