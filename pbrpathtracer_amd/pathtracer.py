@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Sequence
 
 import numpy as np
@@ -37,11 +38,19 @@ HOST_SYMBOLS = [
 ]
 
 _bound = False
+_bind_lock = threading.Lock()
 
 
 def lib() -> C.CDLL:
-    global _bound
     L = _ptk.load()
+    if _bound:
+        return L
+    with _bind_lock:                 # (the prototypes are complete before any thread's first call: a pointer returned through
+        return _bind_locked(L)       # ctypes' default int would be cut to 32 bits)
+
+
+def _bind_locked(L) -> C.CDLL:
+    global _bound
     if _bound:
         return L
     vp, i32, f32 = C.c_void_p, C.c_int, C.c_float

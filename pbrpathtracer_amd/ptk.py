@@ -7,6 +7,7 @@ boundary's flat layout (see include/ptk.h `ptk_scene_desc`).
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import os
 from typing import Optional
 
@@ -73,8 +74,19 @@ SYMBOLS = [
 ]
 
 
+_load_lock = threading.Lock()
+
+
 def load() -> C.CDLL:
     """Load libptk.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _load_lock:                 # (two threads' first calls: ONE library object gets the prototypes, everybody uses that one)
+        return _load_locked()
+
+
+def _load_locked() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib

@@ -315,6 +315,49 @@ def test_bound_handoff_buffer_tracks_every_frame(tmp_path, oracle_mod):
         del out, out2
 
 
+def test_two_tracers_render_concurrently_from_two_threads(tmp_path, oracle_mod):
+    """Two PathTracer instances on the same GPU driven by two host threads at once (each context has its own streams, queues and
+    buffers; nothing is shared but the device): scene loads, BVH builds, renders in small batches and hand-offs interleave
+    freely, and each accumulator equals the oracle's for its own scene."""
+    import threading
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
+    jobs = []
+    for k, (cfg, kw) in enumerate([("C1", dict(width=88, height=64, depth=4)), ("C4", dict(width=72, height=56, depth=5, grid=16))]):
+        d = tmp_path / f"s{k}"; d.mkdir()
+        jobs.append(S.build_config(cfg, str(d), **kw))
+    results = [None, None]; errors = []
+
+    def work(k):
+        try:
+            pts, scene, _ = jobs[k]
+            for rep in range(3):                                        # (loads and builds overlap the other thread's renders)
+                pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(100 + k); pt.SetCameraAperture(0.0)
+                out = pt.AllocOutImage(); pt.SetOutImage(out); pt.ResetImage()
+                for _ in range(12):
+                    pt.RenderFrames(1 + (k + rep) % 3)
+                assert pt.LastError() == ""
+                results[k] = (pt.ReadAccumulation(), pt.GetSamples(), pt.StagedScene(), np.array(out), pt.GetResolution(), pt.GetTraceDepth())
+                pt.SetOutImage(None)
+                if rep < 2: pt.close()
+                else: results[k] += (pt,)
+        except Exception as e:                                          # surfaced in the main thread
+            errors.append((k, repr(e)))
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads: t.start()
+    for t in threads: t.join(timeout=300)
+    assert not errors and all(not t.is_alive() for t in threads), errors
+    for k in range(2):
+        got, n, staged, out8, (W, H), Dp, pt = results[k]
+        cam = camera_from_scene(jobs[k][1]); cam["aperture"] = 0.0
+        o = oracle_mod.Oracle(staged)
+        ocam = oracle_mod.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+        ref, ref8 = o.render(ocam, W, H, Dp, 0, n, 100 + k)
+        o.close()
+        assert np.array_equal(got, ref) and np.array_equal(out8, ref8), k
+        pt.close()
+
+
 def test_device_resident_handoff_buffer(tmp_path):
     """ptk_bind_out_device (N3 without the PCIe hop: the frameTex <- texData upload of main.cpp:3026-3029 for a display path
     that lives on the GPU): the accumulate kernel's 8-bit image lands in a caller-owned DEVICE buffer - here a torch tensor -
