@@ -37,6 +37,9 @@ def arrays_from_ref(ref, scene) -> dict:
                     w = C.c_int(); h = C.c_int()
                     ok = ref.lib.ref_image_load(p.encode(), C.byref(w), C.byref(h))
                     if not ok:
+                        # the material keeps its Image - one without data, which samples as 0 (image.cpp:65-66): a texture of zero extent
+                        m["tex"][s] = len(textures)
+                        textures.append((0, 0, off))
                         continue
                     data = np.zeros(w.value * h.value * 4, np.uint8)
                     ref.lib.ref_image_data(data.ctypes.data_as(C.POINTER(C.c_ubyte)))

@@ -612,7 +612,9 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     if ((uint64_t)n * (uint64_t)(TRI_F4 * sizeof(float4)) > 0xffffffffull)
         return fail(c, PTK_ERR_LIMIT, "more triangles than the kernels' 32-bit record offsets address (89 478 485)");
     if (s->num_lights > 0 && !s->lights) return fail(c, PTK_ERR_BAD_ARG, "null light array");
-    if (s->num_textures > 0 && (!s->textures || !s->texels)) return fail(c, PTK_ERR_BAD_ARG, "null texture array");
+    // (a scene whose textures are ALL missing files - a .pts moved to another machine - has texture entries of zero extent and not
+    // one texel: no atlas to point to)
+    if (s->num_textures > 0 && (!s->textures || (!s->texels && s->texel_bytes > 0))) return fail(c, PTK_ERR_BAD_ARG, "null texture array");
     for (int32_t i = 0; i < n; i++)
         if (s->material[i] < 0 || s->material[i] >= s->num_materials)
             return fail(c, PTK_ERR_BAD_ARG, "triangle material index out of range");

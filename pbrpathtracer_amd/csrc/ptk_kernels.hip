@@ -635,7 +635,7 @@ __device__ __forceinline__ bool sample_direct_light(const PT& P, v3 p, v3 n, v3 
     lt0 = make_float4(l0.x, l0.y, l0.z, l1.x - l0.x);
     lt1 = make_float4(l1.y - l0.y, l1.z - l0.z, l2.x - l0.x, l2.y - l0.y);
     lt2 = make_float4(l2.z - l0.z, l0.w, l3.y, 0.0f);
-    if (!(ndl > 0.0f)) return false;
+    if (ndl <= 0.0f) return false;              // (:519 in its own form: a NaN normal - a normal map on a mesh without uvs - goes ON, as there)
     v3 lColor = V(l1.w, l2.w, l3.x);
     di = muls(mulv(lColor, diffuse), ndl);      // :530
     return true;

@@ -95,6 +95,12 @@ def test_missing_texture_samples_as_zero(ctx, oracle_mod):
     a["textures"]["width"][0] = 0; a["textures"]["height"][0] = 0
     ref, ref8, got, got8 = _both(ctx, oracle_mod, a, _cam(z), 40, 30, 4, 4)
     assert np.array_equal(ref, got)
+    # ... and a scene ALL of whose textures are missing files (a .pts moved to another machine): texture entries without a single
+    # texel behind them still upload and render (found by tools/soak_api.py: the upload refused the empty atlas)
+    a["textures"]["width"][:] = 0; a["textures"]["height"][:] = 0; a["textures"]["offset"][:] = 0
+    a["texels"] = np.zeros(0, np.uint8)
+    ref, ref8, got, got8 = _both(ctx, oracle_mod, a, _cam(z), 40, 30, 4, 4)
+    assert np.array_equal(ref, got) and ref.any()
 
 
 def test_many_spp_chunks_and_passes(ctx, oracle_mod):

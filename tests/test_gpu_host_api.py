@@ -315,6 +315,40 @@ def test_bound_handoff_buffer_tracks_every_frame(tmp_path, oracle_mod):
         del out, out2
 
 
+def test_textures_set_after_the_build_take_effect_even_where_they_make_nans(tmp_path, oracle_mod):
+    """Set...TextureForElement after BuildBVH and a first render (pathtracer.cpp:147-241: the triangles point at the materials, so the
+    next RenderFrame sees the new Image): a present file and a MISSING one (an Image without data samples as 0), on the diffuse,
+    normal and roughness slots.  The Cornell shell has no texture coordinates, so its tangent frames are NaN and a normal map
+    turns every path through that wall into NaN - in the reference (DirectIllumimation's `dot <= 0` test lets a NaN pass,
+    :519), in the oracle, and in the kernels: the same pixels are NaN, every other pixel is equal bit for bit (found by
+    tools/soak_api.py: the kernel's negated form of that test had sent NaNs the other way)."""
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
+    pts, scene, _ = S.build_config("C1", str(tmp_path), width=96, height=64)
+    good = str(tmp_path / "t.ppm"); S.write_ppm(good, S.tex_checker(16, 4))
+    cam = camera_from_scene(scene); cam["aperture"] = 0.0
+    nan_cases = 0
+    for tf in (good, str(tmp_path / "missing.ppm")):
+        for slot in (0, 1, 3):
+            for flat in (1, 0):
+                pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetCameraAperture(0.0); pt.SetSeed(3)
+                pt.RenderFrames(1)
+                pt.context().set_option("flat", flat)
+                pt._set_tex(slot, 0, 4, tf)
+                pt.ResetImage(); pt.RenderFrames(3)
+                assert pt.LastError() == ""
+                got = pt.ReadAccumulation(); st = pt.StagedScene()
+                assert st["materials"]["tex"][4][slot] == 0 and len(st["textures"]) == 1
+                o = oracle_mod.Oracle(st)
+                ocam = oracle_mod.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+                ref, _ = o.render(ocam, 96, 64, pt.GetTraceDepth(), 0, 3, 3)
+                o.close()
+                assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(ref, got, equal_nan=True), (tf, slot, flat)
+                nan_cases += int(np.isnan(ref).any())
+                pt.close()
+    assert nan_cases == 4                                               # the normal slot, both files, both kernels
+
+
 def test_two_tracers_render_concurrently_from_two_threads(tmp_path, oracle_mod):
     """Two PathTracer instances on the same GPU driven by two host threads at once (each context has its own streams, queues and
     buffers; nothing is shared but the device): scene loads, BVH builds, renders in small batches and hand-offs interleave

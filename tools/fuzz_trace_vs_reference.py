@@ -40,7 +40,7 @@ for seed in range(first, first + count):
         m.translucency = float(rng.choice([0.0, 1.0, rng.uniform(0.0, 1.0)])); m.ior = float(rng.choice([1.0, 1.33, 1.5, rng.uniform(1.0, 2.4)]))
         for slot, pool in (("diffuse", ("chk", "noise")), ("normal", ("nrm",)), ("emissive", ("dim",)), ("roughness", ("noise", "chk")),
                            ("metallic", ("noise", "dots"))):          # (no opacity maps: the reference draws once per LEAF VISITED, in the order of its per-run random tree - DESIGN.md section 2, difference 4 - which no tape can replay)
-            if rng.uniform() < 0.2: m.textures[slot] = paths[str(rng.choice(pool))]
+            if rng.uniform() < 0.2: m.textures[slot] = paths[str(rng.choice(pool))] if rng.uniform() < 0.8 else os.path.join(tmp, "missing.ppm")      # (a file that is not there samples as 0)
     obj = os.path.join(tmp, "scene.obj")
     S.write_obj(obj, groups)
     sc.objects.append(S.ObjectDesc(obj, "scene", [S.ElementDesc(g.name, m) for g, m in zip(groups, mats)]))

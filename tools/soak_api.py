@@ -1,6 +1,6 @@
 """GPU box, one-off: random sequences of host-API calls on the drop-in PathTracer (camera, projection, lens, resolution, trace
 depth, seed, material edits after BuildBVH, another scene file into the same tracer, tile splits, Exit() with nothing in flight,
-the pooled kernel switched on and off, hand-off buffers of every kind coming and going, sample batching, a second tracer on the same GPU) - after every stage the
+the pooled kernel switched on and off, textures set on any slot after the build, hand-off buffers of every kind coming and going, sample batching, a second tracer on the same GPU) - after every stage the
 accumulator must be the oracle's for the state the calls left behind.  python tools/soak_api.py [first_seed] [count]"""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,6 +20,10 @@ built = {}
 for name, kw in cfgs:
     d = os.path.join(tmp, name); os.makedirs(d)
     built[name] = S.build_config(name, d, **kw)
+tex_files = []
+for k, img in enumerate((S.tex_checker(16, 4), S.tex_noise(32, 5, 0, 255, 4), S.tex_dots(8, 2, 0.4))):
+    tex_files.append(os.path.join(tmp, f"t{k}.ppm")); S.write_ppm(tex_files[-1], img)
+tex_files.append(os.path.join(tmp, "missing.ppm"))
 bad = 0; t0 = time.time(); stages = 0
 for k in range(count):
     seed = first + k
@@ -32,7 +36,7 @@ for k in range(count):
     st = dict(W=pt.GetResolution()[0], H=pt.GetResolution()[1], D=pt.GetTraceDepth(), seed=0, tile=(0, 1))
     out_img = None
     for stage in range(int(rng.integers(3, 8))):
-        op = int(rng.integers(0, 12))
+        op = int(rng.integers(0, 13))
         # the hand-off buffer comes and goes, pageable (page-locked in place) or from AllocOutImage
         if rng.uniform() < 0.5:
             kind = int(rng.integers(0, 4))                # (3: a device buffer - a torch tensor - through SetOutDeviceImage)
@@ -68,6 +72,14 @@ for k in range(count):
             w = int(rng.integers(1, 6)); st["tile"] = (int(rng.integers(0, w)), w); pt.SetTile(*st["tile"])
         elif op == 10:
             pt.Exit()                                        # nothing in flight: must not disturb what follows
+        elif op == 12:
+            # a texture set (or re-set: the reference reloads the Image in place, pathtracer.cpp:147-241) after the scene has been
+            # built and rendered: any slot, files of three sizes and one that does not exist (samples as 0)
+            objs = pt.GetLoadedObjects(); ob = int(rng.integers(0, len(objs)))
+            if objs[ob]:
+                el = int(rng.integers(0, objs[ob])); slot = int(rng.integers(0, 6))
+                tf = str(rng.choice(tex_files)); pt._set_tex(slot, ob, el, tf)
+                if os.environ.get("SOAK_VERBOSE"): print(f"    texture: object {ob} element {el} slot {slot} <- {os.path.basename(tf)}", flush=True)
         else:
             c = pt.context(); pooled = bool(rng.integers(0, 2))
             c.set_option("persistent", 1 if pooled else -1); c.set_option("pool", int(rng.choice([64, 128, 256])) if pooled else 0)
@@ -101,7 +113,7 @@ for k in range(count):
         elif out_img is not None and not np.array_equal(out_img.cpu().numpy() if torch.is_tensor(out_img) else np.asarray(out_img), ref8):
             bad += 1
             print(f"HAND-OFF MISMATCH seed {seed} {name} stage {stage} op {op} state {st} buffer {type(out_img).__name__}", flush=True)
-        if err or got.shape != ref.shape or not np.array_equal(got, ref):
+        if err or got.shape != ref.shape or not np.array_equal(got, ref, equal_nan=True):       # (NaN where the reference has NaN: a normal map on a mesh without uvs)
             bad += 1
             print(f"MISMATCH seed {seed} {name} stage {stage} op {op} state {st} aperture {cam['aperture']} err '{err}'", flush=True)
     pt.SetOutDeviceImage(None); pt.SetOutImage(None); pt.close(); other.close(); out_img = None
