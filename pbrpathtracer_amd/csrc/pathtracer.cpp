@@ -590,7 +590,16 @@ void PathTracer::ClearScene()                                           // :281-
     m->have_resolution = false;                                        // mTotalImg is freed (:292-294)
 }
 
-void PathTracer::SetOutImage(GLubyte* out) { m->out_img = out; if (out) { m->out_gl = 0; m->out_dev = 0; } }       // :297-300
+// :297-300.  The buffer the device layer holds page-locked (ptk_bind_out_image) is let go HERE, not at the next RenderFrame():
+// the viewer frees texData and allocates the next one right around this call (main.cpp:3433-3445), and memory that is freed
+// while still registered with the runtime poisons whatever the allocator puts there next (found by tools/soak_api.py: a later
+// scene upload staged its triangles in such a range and the copy to the device was refused).
+void PathTracer::SetOutImage(GLubyte* out)
+{
+    if (out != m->bound_img && m->bound_img && m->ctx) { m->note(ptk_bind_out_image(m->ctx, 0)); m->bound_img = 0; }
+    m->out_img = out;
+    if (out) { m->out_gl = 0; m->out_dev = 0; }
+}
 
 void PathTracer::SetResolution(const glm::ivec2& res)                  // :302-306
 {

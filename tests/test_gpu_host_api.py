@@ -299,6 +299,16 @@ def test_bound_handoff_buffer_tracks_every_frame(tmp_path, oracle_mod):
         # a new resolution: the caller reallocates its buffer and hands it over again (main.cpp:3425-3446)
         pt.SetResolution((64, 48))
         out2 = np.full((48, 64, 3), 5, np.uint8)
+        if not pinned:
+            # the caller's buffer is page-locked in place while bound - and let go by SetOutImage ITSELF, not at the next render:
+            # main.cpp:3433-3445 frees texData right around that call, and memory freed while still registered poisons whatever
+            # the allocator puts there next (found by tools/soak_api.py)
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so"); dev_alias = ctypes.c_void_p(0)
+            assert hip.hipHostGetDevicePointer(ctypes.byref(dev_alias), ctypes.c_void_p(out.ctypes.data), 0) == 0     # registered now
+            pt.SetOutImage(out2)
+            assert hip.hipHostGetDevicePointer(ctypes.byref(dev_alias), ctypes.c_void_p(out.ctypes.data), 0) != 0     # ... and not any more
+            hip.hipGetLastError()
         pt.SetOutImage(out2); pt.ResetImage(); pt.RenderFrame()
         dev2 = np.zeros((48, 64, 3), np.uint8); ctx = pt.context(); ctx.L.ptk_resolve_rgb8(ctx.h, dev2.ctypes.data)
         assert np.array_equal(out2, dev2) and out2.any()

@@ -1,6 +1,6 @@
 """GPU box, one-off: random sequences of host-API calls on the drop-in PathTracer (camera, projection, lens, resolution, trace
 depth, seed, material edits after BuildBVH, another scene file into the same tracer, tile splits, Exit() with nothing in flight,
-the pooled kernel switched on and off, textures set on any slot after the build, hand-off buffers of every kind coming and going, sample batching, a second tracer on the same GPU) - after every stage the
+the pooled kernel switched on and off, textures set on any slot after the build, BuildBVH again, further objects loaded into the scene, hand-off buffers of every kind coming and going, sample batching, a second tracer on the same GPU) - after every stage the
 accumulator must be the oracle's for the state the calls left behind.  python tools/soak_api.py [first_seed] [count]"""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,7 +36,7 @@ for k in range(count):
     st = dict(W=pt.GetResolution()[0], H=pt.GetResolution()[1], D=pt.GetTraceDepth(), seed=0, tile=(0, 1))
     out_img = None
     for stage in range(int(rng.integers(3, 8))):
-        op = int(rng.integers(0, 13))
+        op = int(rng.integers(0, 15))
         # the hand-off buffer comes and goes, pageable (page-locked in place) or from AllocOutImage
         if rng.uniform() < 0.5:
             kind = int(rng.integers(0, 4))                # (3: a device buffer - a torch tensor - through SetOutDeviceImage)
@@ -80,6 +80,19 @@ for k in range(count):
                 el = int(rng.integers(0, objs[ob])); slot = int(rng.integers(0, 6))
                 tf = str(rng.choice(tex_files)); pt._set_tex(slot, ob, el, tf)
                 if os.environ.get("SOAK_VERBOSE"): print(f"    texture: object {ob} element {el} slot {slot} <- {os.path.basename(tf)}", flush=True)
+        elif op == 13:
+            pt.BuildBVH()                                    # again: the light list follows the materials as they are now (pathtracer.cpp:267-273)
+        elif op == 14:
+            # one more object into the loaded scene (LoadObject + SetMaterial + BuildBVH, previewer.cpp:770-817): a quad or a small fan, sometimes a light
+            k = len(pt.GetLoadedObjects())
+            extra = os.path.join(tmp, f"extra_{seed}_{stage}.obj")
+            cx, cy, cz = rng.uniform(-0.5, 0.5, 3)
+            open(extra, "w").write("".join(f"v {cx + dx:.4f} {cy + dy:.4f} {cz + 0.1 * dx * dy:.4f}\n" for dx, dy in ((-.2, -.2), (.2, -.2), (.25, .2), (-.2, .25), (0, .4)))
+                                   + "vn 0 0 -1\n" + ("f 1//1 2//1 3//1 4//1\n" if rng.uniform() < 0.5 else "f 1//1 2//1 3//1 4//1 5//1\n"))
+            pt.LoadObject(extra, np.eye(4, dtype=np.float32))
+            mm = np.array([0, *rng.uniform(0.2, 0.9, 3), 0.5, 0.5, 0.5, *((1.0, 0.9, 0.8) if rng.uniform() < 0.4 else (0, 0, 0)), float(rng.uniform(1, 4)), 1.0, 0.0, 0.0, 1.5], np.float32)
+            pt.SetMaterial(k, 0, mm)
+            pt.BuildBVH()
         else:
             c = pt.context(); pooled = bool(rng.integers(0, 2))
             c.set_option("persistent", 1 if pooled else -1); c.set_option("pool", int(rng.choice([64, 128, 256])) if pooled else 0)
