@@ -144,8 +144,10 @@ int ptk_resolve_rgb8(ptk_ctx* ctx, uint8_t* host_out);
  * for the stream - no copy command, no second launch.  A buffer from ptk_host_alloc is used as it is; any other buffer
  * (`new GLubyte[w*h*3]`, main.cpp:3435) is page-locked in place for as long as it is bound.  If neither works the call
  * still succeeds and ptk_resolve_rgb8 copies as before.  NULL unbinds; ptk_set_frame with another resolution unbinds too
- * (the caller reallocates texData then, main.cpp:3425-3446).  The buffer stays caller-owned; while bound, renders run on
- * the context's stream alone (each frame is waited for anyway). */
+ * (the caller reallocates texData then, main.cpp:3425-3446).  The buffer stays caller-owned and must stay ALLOCATED while it is
+ * bound: unbind (NULL, or bind its successor) BEFORE freeing it - memory freed while still page-locked through the runtime
+ * poisons whatever the allocator places there next (PathTracer::SetOutImage does this for the class's users).  While bound,
+ * renders run on the context's stream alone (each frame is waited for anyway). */
 int ptk_bind_out_image(ptk_ctx* ctx, uint8_t* host_out);
 /* The same hand-off without the PCIe hop, for a display path that lives on the GPU (N3: the viewer's frameTex ← texData upload,
  * main.cpp:3026-3029, :3425-3446).  The accumulate kernel writes the 8-bit image - W*H*3 bytes, RGB, rows bottom-up, the layout
