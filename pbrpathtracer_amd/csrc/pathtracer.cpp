@@ -596,7 +596,10 @@ void PathTracer::ClearScene()                                           // :281-
 // scene upload staged its triangles in such a range and the copy to the device was refused).
 void PathTracer::SetOutImage(GLubyte* out)
 {
-    if (out != m->bound_img && m->bound_img && m->ctx) { m->note(ptk_bind_out_image(m->ctx, 0)); m->bound_img = 0; }
+    // (even when the new pointer EQUALS the old one: a buffer freed and allocated again at the same address - mmap'd blocks of a
+    // few megabytes do that - has other pages behind it than the ones that were locked)
+    if (m->bound_img && m->ctx) { m->note(ptk_bind_out_image(m->ctx, 0)); m->bound_img = 0; }
+    m->bind_dirty = true;
     m->out_img = out;
     if (out) { m->out_gl = 0; m->out_dev = 0; }
 }
