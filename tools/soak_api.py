@@ -46,7 +46,7 @@ for k in range(count):
         elif op == 1:
             cam["aperture"] = float(rng.choice([0.0, 0.03])); pt.SetCameraAperture(cam["aperture"])
         elif op == 2:
-            st["W"], st["H"] = int(rng.integers(8, 130)), int(rng.integers(8, 90)); pt.SetResolution((st["W"], st["H"]))
+            st["W"], st["H"] = int(rng.integers(1, 130)), int(rng.integers(1, 90)); pt.SetResolution((st["W"], st["H"]))
         elif op == 3:
             st["D"] = int(rng.integers(1, 9)); pt.SetTraceDepth(st["D"])
         elif op == 4:
