@@ -6,6 +6,7 @@ set -e
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"; W=${TMPDIR:-/tmp}/ptk_asan_images; rm -rf $W; mkdir -p $W; cd $W
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -I$ROOT/include -I$ROOT/pbrpathtracer_amd/csrc $ROOT/pbrpathtracer_amd/csrc/image.cpp $ROOT/tools/asan/image_harness.cpp -lz -o img_asan
 python3 $ROOT/tools/asan/corrupt_images.py corrupt 0 ${1:-1000} > /dev/null
+set +e
 ls corrupt > list.txt; split -l 40 list.txt batch_; flagged=0
 for b in batch_*; do
   if ! timeout 40 ./img_asan $(sed 's#^#corrupt/#' $b | tr '\n' ' ') > out.txt 2>&1; then
