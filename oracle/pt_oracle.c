@@ -50,6 +50,11 @@ static inline v3 reflect(v3 I, v3 N)
 /* ---- sin/cos on [0, 2*pi] -------------------------------------------------------------------
  * Replaces libm cosf/sinf (pathtracer.cpp:610, :738) by a fixed polynomial so that CPU and GPU
  * agree bit for bit.  Reduction in double, cephes single-precision kernels on [-pi/4, pi/4]. */
+#ifdef ORC_LIBM_SINCOS
+/* (tools/fuzz_trace_vs_reference.py --libm: libm's own sinf / cosf, as the reference calls them - with these the recursion below
+ * reproduces the reference's radiance BIT FOR BIT; the polynomial is what the product computes with, DESIGN.md section 2, difference 6) */
+void orc_sincos(float a, float* s, float* c) { *s = sinf(a); *c = cosf(a); }
+#else
 void orc_sincos(float a, float* s, float* c)
 {
     int k = (int)(a * 0.636619772367581343f + 0.5f);
@@ -66,6 +71,7 @@ void orc_sincos(float a, float* s, float* c)
     default: *s = -cp; *c = sp; break;
     }
 }
+#endif
 
 /* ---- RNG -------------------------------------------------------------------------------------
  * Replaces PathTracer::Rand (pathtracer.cpp:367-371; one std::mt19937 raced by all workers) by a

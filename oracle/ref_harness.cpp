@@ -273,6 +273,15 @@ void ref_trace(const float* ro, const float* rd, float* out3)
     out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
 }
 
+// ... entered at any point of a path: Trace's own depth / iter / inside arguments, the engine advanced by `skip` draws first
+// (debugging aid of tools/fuzz_trace_vs_reference.py: where along a path does a replay part ways with the reference)
+void ref_trace_state(const float* ro, const float* rd, int depth, int iter, int inside, int skip, float* out3)
+{
+    for (int i = 0; i < skip; i++) g_pt.mRng();
+    glm::vec3 c = g_pt.Trace(glm::vec3(ro[0], ro[1], ro[2]), glm::vec3(rd[0], rd[1], rd[2]), depth, iter, inside != 0);
+    out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
+}
+
 void ref_sample_circle(float* out2)
 {
     glm::vec2 c = g_pt.SampleCircle();

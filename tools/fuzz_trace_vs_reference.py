@@ -2,7 +2,9 @@
 random scenes - the Cornell shell plus two to four spheres, every material field drawn at random (type, colours, emission, roughness,
 reflectiveness, translucency, index of refraction, smoothing) and any of the six texture slots filled at random - with the
 reference's own draws replayed from a tape (tier T's mechanism, oracle/gen_golden.py): the radiance must agree to 1e-5 relative and
-exactly as many draws must be consumed.   python3 tools/fuzz_trace_vs_reference.py [first_seed] [scenes] [paths_per_scene]"""
+exactly as many draws must be consumed.   python3 tools/fuzz_trace_vs_reference.py [--libm] [first_seed] [scenes] [paths_per_scene]
+Round 3: 80 000 paths - with --libm every one bit-identical (NaN paths included); with the oracle's own sin/cos polynomial 17 part ways where a
+last-bit change of a bounce direction lands in the neighbouring texel of a nearest-texel lookup."""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +14,15 @@ from oracle.ref_binding import Ref
 from oracle.ref_scene import arrays_from_ref
 from oracle import oracle_binding as OB
 OB.build()
+if "--libm" in sys.argv:
+    # the oracle with libm's sinf / cosf in place of its polynomial (oracle/pt_oracle.c ORC_LIBM_SINCOS): the one arithmetic difference
+    # to the reference taken away, the replay must then agree BIT FOR BIT
+    import subprocess
+    sys.argv.remove("--libm")
+    alt = os.path.join(tempfile.gettempdir(), "libptoracle_libm.so")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-fopenmp", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-DORC_LIBM_SINCOS", "-shared", "-o", alt,
+                           os.path.join(ROOT, "oracle", "pt_oracle.c"), "-lm"])
+    OB.LIB_PATH = alt
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 npaths = int(sys.argv[3]) if len(sys.argv) > 3 else 200
