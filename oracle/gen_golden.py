@@ -303,6 +303,31 @@ def tier_s(ref: Ref, tmp: str):
 
 
 
+def tier_f(ref: Ref, tmp: str):
+    """Whole frames, deterministically: RenderFrame (pathtracer.cpp:741-817) run on ONE OpenMP thread - its own rule leaves one worker
+    of four, :768-775 - consumes its single mt19937 in pixel order, so the draws can be put on a tape and the frame replayed
+    (oracle orc_render_tape): camera rays incl. the incremental row walk and the lens sample, every path, the accumulation and its
+    bottom-up layout.  The camera stands at an irrational pose: through pixel CORNERS at the default pose rays run along seams and
+    box faces, where the reference's own answer depends on its per-run random tree."""
+    for kind, (W, H), depth, camf, fd in [("cornell", (21, 13), 4, 1.0e9, 3.5), ("textured", (17, 12), 5, 2.0, 3.2), ("glass", (14, 15), 6, 8.0, 3.4), ("glossy", (9, 20), 5, 1.0e9, 3.5)]:
+        sc = micro_scene(kind, tmp)
+        sc.trace_depth = depth; sc.width, sc.height = W, H; sc.camera_f = camf; sc.focal_dist = fd
+        sc.cam_pos = (0.0137, 0.0071, -3.5); sc.cam_rot = (0.731, -0.417, 0.293)
+        ref.load_scene(sc)
+        arr = arrays_from_ref(ref, sc)
+        cam, proj = camera_dict(ref)
+        ref.lib.ref_seed(777 + len(kind))
+        tape = ref.peek_tape(W * H * 300)
+        ref.lib.ref_mark()
+        ref.render(1, threads=4)
+        nd = ref.lib.ref_draws_since_mark(len(tape))
+        assert nd > 0
+        save(f"tier_f_{kind}.npz", width=np.int32(W), height=np.int32(H), depth=np.int32(depth), cam=cam, proj=proj, focal_dist=np.float32(sc.focal_dist),
+             aperture=np.float32(np.float32(S.PTS_FOCAL) / np.float32(sc.camera_f)), tape=tape[: nd + 8], ndraws=np.int32(nd), total=ref.total(W, H),
+             rgb8=ref.rgb8(W, H), **scene_arrays_dict(arr))
+        print("  frame", kind, (W, H), "draws", nd)
+
+
 def tier_k_images(ref: Ref, tmp: str):
     """Texture ingest (Image::Load -> stbi_load(..., 4), image.cpp:38-61): encoded files + the RGBA8 the
     reference decodes them to.  Files are produced with Pillow; the expected texels come from the
@@ -827,7 +852,7 @@ def tier_k_resize(ref: Ref, tmp: str):
 def main():
     ref = Ref()
     with tempfile.TemporaryDirectory() as tmp:
-        only = {"psd_pic": tier_k_images_psd_pic, "obj_variants": tier_k_obj_variants, "jpeg_sampling": tier_k_images_jpeg_sampling}
+        only = {"frames": tier_f, "psd_pic": tier_k_images_psd_pic, "obj_variants": tier_k_obj_variants, "jpeg_sampling": tier_k_images_jpeg_sampling}
         if len(sys.argv) > 1 and sys.argv[1] in only:          # only one of the fixtures added last (the others stay as committed)
             only[sys.argv[1]](ref, tmp)
             return
@@ -839,6 +864,7 @@ def main():
         tier_k_resize(ref, tmp)
         tier_k_scene(ref, tmp)
         tier_t(ref, tmp)
+        tier_f(ref, tmp)
         tier_s(ref, tmp)
 
 

@@ -143,6 +143,15 @@ class Oracle:
                             total.ctypes.data, rgb.ctypes.data if rgb is not None else None, threads)
         return total, rgb
 
+    def render_tape(self, cam: CameraC, width, height, depth, tape):
+        """One RenderFrame with the reference's draws on tape (its single-thread pixel order); returns (total, draws consumed)."""
+        total = np.zeros((height, width, 3), dtype=np.float32)
+        tape = np.ascontiguousarray(tape, np.float32)
+        self.lib.orc_render_tape.restype = C.c_int
+        self.lib.orc_render_tape.argtypes = [C.c_void_p, C.POINTER(CameraC), C.c_int, C.c_int, C.c_int, _f, C.c_int, _f]
+        n = self.lib.orc_render_tape(self.h, C.byref(cam), width, height, depth, self._p(tape), len(tape), self._p(total))
+        return total, n
+
     def primary_dirs(self, cam: CameraC, width, height):
         out = np.zeros((height, width, 3), dtype=np.float32)
         self.lib.orc_primary_dirs(C.byref(cam), width, height, out.ctypes.data)

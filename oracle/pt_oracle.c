@@ -815,3 +815,37 @@ void orc_render(const orc_scene* s, const orc_camera* cam, int W, int H, int D,
     }
     free(dirs_all);
 }
+
+/* RenderFrame (pathtracer.cpp:741-817) for ONE frame with the draws of the reference's single engine on tape, in the order its
+ * loop consumes them when it runs on one thread: rows top to bottom, columns left to right, per pixel the two draws of
+ * SampleCircle (:736-737) and then the path's (recursive form, g++'s operand order).  Adds into `total` (rows bottom-up, :796)
+ * and returns the number of draws consumed.  Test infrastructure for tools/fuzz_frame_vs_reference.py. */
+int orc_render_tape(const orc_scene* s, const orc_camera* cam, int W, int H, int D, const float* tape, int tape_len, float* total)
+{
+    frame_t f; frame_setup(cam, W, H, &f);
+    float* dirs = (float*)malloc((size_t)W * 3 * sizeof(float));
+    rng_t r; rng_init(&r, 0, 0);
+    r.tape = tape; r.tape_len = tape_len; r.tape_pos = 0;
+    for (int i = 0; i < H; i++)
+    {
+        primary_row(&f, W, i, dirs);
+        for (int j = 0; j < W; j++)
+        {
+            size_t px = ((size_t)(H - 1 - i) * W + j) * 3;
+            v3 rayDir0 = ld3(dirs + j * 3);
+            v3 camPos = f.pos;
+            v3 focalPoint = add(camPos, muls(rayDir0, cam->focal_dist));
+            float r1 = rnd(&r), r2 = rnd(&r), off[2];
+            orc_sample_circle(r1, r2, off);
+            off[0] = off[0] * cam->aperture; off[1] = off[1] * cam->aperture;
+            camPos = add(camPos, add(muls(f.right, off[0]), muls(f.up, off[1])));
+            v3 rayDir = normalize(sub(focalPoint, camPos));
+            uint32_t ray = 0;
+            v3 color = trace_rec(s, camPos, rayDir, D, 0, 0, 0, &r, &ray, 1);
+            total[px] += color.x; total[px + 1] += color.y; total[px + 2] += color.z;
+        }
+    }
+    free(dirs);
+    return r.tape_pos;
+}
+

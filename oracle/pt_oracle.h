@@ -94,6 +94,7 @@ void orc_render(const orc_scene* s, const orc_camera* cam, int width, int height
 /* Primary ray directions before DOF, row-major top-down [H][W][3]; follows the incremental
  * `pixel += camRight*deltaX` arithmetic of pathtracer.cpp:755-766,782-785,814. */
 void orc_primary_dirs(const orc_camera* cam, int width, int height, float* out);
+int orc_render_tape(const orc_scene* s, const orc_camera* cam, int width, int height, int max_depth, const float* tape, int tape_len, float* total);
 
 /* Radiance of one path with the draws taken from `tape` (tier T).  Returns #draws consumed. */
 int orc_trace_tape(const orc_scene* s, const float* ro, const float* rd, int max_depth,

@@ -1,0 +1,91 @@
+"""THIS CONTAINER ONLY (needs oracle/_ref built from /root/reference): one whole PathTracer::RenderFrame() of the REAL reference - run on one
+OpenMP thread, so that its single mt19937 is consumed in pixel order - against the oracle replaying the same draws from a tape
+(orc_render_tape), on the random scenes of fuzz_trace_vs_reference.py, pinhole and thin-lens cameras, random resolutions: camera rays
+(the incremental row walk, the lens sample), every path, the accumulation and its bottom-up layout.  With --libm (libm's sinf / cosf
+compiled into the oracle) the frames must be BIT-IDENTICAL; without, within 1e-5 relative per pixel except where a path parts ways
+(see fuzz_trace_vs_reference.py).   python3 tools/fuzz_frame_vs_reference.py [--libm] [first_seed] [scenes]"""
+
+import os, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from pbrpathtracer_amd import scenes as S
+from oracle.ref_binding import Ref, _fp
+from oracle.ref_scene import arrays_from_ref
+from oracle import oracle_binding as OB
+OB.build()
+libm = "--libm" in sys.argv
+if libm:
+    # the oracle with libm's sinf / cosf in place of its polynomial (oracle/pt_oracle.c ORC_LIBM_SINCOS): the one arithmetic difference
+    # to the reference taken away, the replay must then agree BIT FOR BIT
+    import subprocess
+    sys.argv.remove("--libm")
+    alt = os.path.join(tempfile.gettempdir(), "libptoracle_libm.so")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-fopenmp", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-DORC_LIBM_SINCOS", "-shared", "-o", alt,
+                           os.path.join(ROOT, "oracle", "pt_oracle.c"), "-lm"])
+    OB.LIB_PATH = alt
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+ref = Ref()
+bad = 0; frames = 0; exact = 0
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    tmp = tempfile.mkdtemp()
+    sc = S.SceneDesc(trace_depth=int(rng.integers(1, 9)), width=64, height=64, focal_dist=3.5, camera_f=1.0e9)
+    groups, mats = S.cornell_groups(uv=bool(seed % 4))                  # (every fourth scene: a shell without texture coordinates - NaN tangent frames, NaN radiance behind a normal map)
+    texs = {"chk": S.tex_checker(32, 4), "nrm": S.tex_normal_waves(32, 2, 0.8), "noise": S.tex_noise(32, seed % 50, 0, 255, 4),
+            "dots": S.tex_dots(32, 4, 0.35), "dim": (S.tex_dots(32, 4, 0.3) // 4).astype(np.uint8)}
+    paths = {}
+    for k, img in texs.items():
+        paths[k] = os.path.join(tmp, k + ".ppm"); S.write_ppm(paths[k], img)
+    for k in range(int(rng.integers(2, 5))):
+        groups.append(S.uv_sphere(f"ball{k}", (float(rng.uniform(-0.6, 0.6)), float(rng.uniform(-0.7, 0.3)), float(rng.uniform(-0.4, 0.4))),
+                                  float(rng.uniform(0.2, 0.4)), 10, 7, smooth=bool(rng.integers(0, 2))))
+        mats.append(S.MaterialDesc())
+    for i, m in enumerate(mats):
+        if i < 6 and rng.uniform() < 0.4: continue                       # some of the shell's own materials stay (incl. the light)
+        m.type = S.TRANSLUCENT if rng.uniform() < 0.35 else S.OPAQUE
+        m.diffuse = tuple(float(x) for x in rng.uniform(0.05, 1.0, 3)); m.specular = tuple(float(x) for x in rng.uniform(0.05, 1.0, 3))
+        if rng.uniform() < 0.15: m.emissive = tuple(float(x) for x in rng.uniform(0.0, 1.0, 3)); m.emissive_intensity = float(rng.uniform(0.5, 6.0))
+        m.roughness = float(rng.choice([0.0, 1.0, rng.uniform(0.0, 1.0)])); m.reflectiveness = float(rng.choice([0.0, 1.0, rng.uniform(0.0, 1.0)]))
+        m.translucency = float(rng.choice([0.0, 1.0, rng.uniform(0.0, 1.0)])); m.ior = float(rng.choice([1.0, 1.33, 1.5, rng.uniform(1.0, 2.4)]))
+        for slot, pool in (("diffuse", ("chk", "noise")), ("normal", ("nrm",)), ("emissive", ("dim",)), ("roughness", ("noise", "chk")),
+                           ("metallic", ("noise", "dots"))):          # (no opacity maps: the reference draws once per LEAF VISITED, in the order of its per-run random tree - DESIGN.md section 2, difference 4 - which no tape can replay)
+            if rng.uniform() < 0.2: m.textures[slot] = paths[str(rng.choice(pool))] if rng.uniform() < 0.8 else os.path.join(tmp, "missing.ppm")      # (a file that is not there samples as 0)
+    obj = os.path.join(tmp, "scene.obj")
+    S.write_obj(obj, groups)
+    sc.objects.append(S.ObjectDesc(obj, "scene", [S.ElementDesc(g.name, m) for g, m in zip(groups, mats)]))
+    # (the camera looks through pixel CORNERS, pathtracer.cpp:785: at its default pose such rays run exactly along seams and box faces,
+    # where the reference's own answer depends on its per-run random tree - DESIGN.md section 2, difference 3; an irrational pose keeps them off)
+    sc.cam_pos = (0.0137 + float(rng.uniform(-0.1, 0.1)), 0.0071 + float(rng.uniform(-0.1, 0.1)), -3.5)
+    sc.cam_rot = (0.731 + float(rng.uniform(-3, 3)), -0.417 + float(rng.uniform(-3, 3)), 0.293 + float(rng.uniform(-5, 5)))
+    W, H = int(rng.integers(3, 40)), int(rng.integers(2, 28))
+    sc.width, sc.height = W, H
+    if rng.uniform() < 0.5: sc.camera_f = float(rng.choice([1.0, 2.0, 8.0])); sc.focal_dist = float(rng.uniform(2.5, 4.0))      # thin lens: aperture = focal / F
+    ref.load_scene(sc)
+    arr = arrays_from_ref(ref, sc)
+    o = OB.Oracle(arr)
+    cam9 = np.zeros(9, np.float32); proj = np.zeros(2, np.float32)
+    ref.lib.ref_get_camera(_fp(cam9)); ref.lib.ref_get_projection(_fp(proj))
+    aperture = float(np.float32(S.PTS_FOCAL) / np.float32(sc.camera_f))
+    ocam = OB.make_camera(cam9[0:3], cam9[3:6], cam9[6:9], float(proj[0]), float(proj[1]), float(sc.focal_dist), aperture)
+    ref.lib.ref_seed(5000 + seed)
+    tape = ref.peek_tape(W * H * 400)
+    ref.lib.ref_mark()
+    ref.render(1, threads=4)                    # RenderFrame's own rule leaves ONE worker of four (pathtracer.cpp:768-775): pixel order
+    nd = ref.lib.ref_draws_since_mark(len(tape))
+    want = ref.total(W, H)
+    if nd < 0: print(f"seed {seed}: more draws than the tape holds, skipped"); continue
+    got, n = o.render_tape(ocam, W, H, sc.trace_depth, tape[: nd + 8])
+    o.close()
+    frames += 1
+    same_bits = np.array_equal(got.view(np.uint32), want.view(np.uint32)) or np.array_equal(got, want, equal_nan=True)
+    rel = np.abs(got - want) / np.maximum(1.0, np.abs(want)); rel[np.isnan(want) & np.isnan(got)] = 0
+    npx = int((rel > 1e-5).any(axis=2).sum())
+    exact += int(same_bits)
+    if n != nd or (libm and not same_bits) or (not libm and npx > max(2, W * H // 50)):
+        bad += 1
+        print(f"MISMATCH seed {seed}: {W}x{H} depth {sc.trace_depth} aperture {aperture:.3g}: draws {n} vs {nd}, pixels off by more than 1e-5: {npx}, bit-identical: {same_bits}", flush=True)
+    if (seed - first) % 10 == 0: print(f"seed {seed}: {W}x{H}, {nd} draws, bit-identical frames so far {exact} of {frames}", flush=True)
+print("frames", frames, "bit-identical", exact, "mismatches", bad)
+sys.exit(1 if bad else 0)
