@@ -3,7 +3,9 @@ OpenMP thread, so that its single mt19937 is consumed in pixel order - against t
 (orc_render_tape), on the random scenes of fuzz_trace_vs_reference.py, pinhole and thin-lens cameras, random resolutions: camera rays
 (the incremental row walk, the lens sample), every path, the accumulation and its bottom-up layout.  With --libm (libm's sinf / cosf
 compiled into the oracle) the frames must be BIT-IDENTICAL; without, within 1e-5 relative per pixel except where a path parts ways
-(see fuzz_trace_vs_reference.py).   python3 tools/fuzz_frame_vs_reference.py [--libm] [first_seed] [scenes]"""
+(see fuzz_trace_vs_reference.py).   python3 tools/fuzz_frame_vs_reference.py [--libm] [first_seed] [scenes]
+Round 3: 500 frames with --libm, 499 bit-identical; in the one other (seed 3011) three pixels differ where the reference's BVH loses a hit that its own
+IntersectTriangle accepts (its box test is not conservative: DESIGN.md section 2, difference 3) - the reference's answer there depends on its per-run tree."""
 
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,7 +29,7 @@ if libm:
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 ref = Ref()
-bad = 0; frames = 0; exact = 0
+bad = 0; frames = 0; exact = 0; edited = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     tmp = tempfile.mkdtemp()
@@ -64,6 +66,28 @@ for seed in range(first, first + count):
     if rng.uniform() < 0.5: sc.camera_f = float(rng.choice([1.0, 2.0, 8.0])); sc.focal_dist = float(rng.uniform(2.5, 4.0))      # thin lens: aperture = focal / F
     ref.load_scene(sc)
     arr = arrays_from_ref(ref, sc)
+    if rng.uniform() < 0.4:
+        # SetMaterial AFTER BuildBVH (pathtracer.cpp:243-258): the triangles point at the materials, so the next frame sees the edit - but
+        # mLights stays as BuildBVH collected it (:267-273): a material that starts to emit makes no light, a light that stops emitting
+        # is still sampled (with a black colour)
+        lights_as_built = arr["lights"].copy()
+        els = sc.objects[0].elements
+        for k in rng.choice(len(els), size=int(rng.integers(1, 3)), replace=False):
+            m = els[int(k)].material
+            m.diffuse = tuple(float(x) for x in rng.uniform(0.05, 1.0, 3)); m.roughness = float(rng.choice([0.0, 1.0, 0.4]))
+            if rng.uniform() < 0.6:
+                if any(m.emissive): m.emissive = (0.0, 0.0, 0.0)
+                else: m.emissive = tuple(float(x) for x in rng.uniform(0.2, 1.0, 3)); m.emissive_intensity = float(rng.uniform(1.0, 5.0))
+            ref.lib.ref_set_material(0, int(k), _fp(m.as_floats()))
+            if rng.uniform() < 0.5:
+                # ... and a texture set after the build (:147-241): a new Image, or the slot's Image reloaded in place
+                slot = int(rng.integers(0, 5)); name = S.TEX_SLOTS[slot]
+                tf = paths[str(rng.choice(["chk", "noise", "dots"]))] if rng.uniform() < 0.8 else os.path.join(tmp, "missing.ppm")
+                m.textures[name] = tf
+                ref.lib.ref_set_texture(0, int(k), slot, tf.encode())
+        arr = arrays_from_ref(ref, sc)
+        arr["lights"] = lights_as_built
+        edited += 1
     o = OB.Oracle(arr)
     cam9 = np.zeros(9, np.float32); proj = np.zeros(2, np.float32)
     ref.lib.ref_get_camera(_fp(cam9)); ref.lib.ref_get_projection(_fp(proj))
@@ -87,5 +111,5 @@ for seed in range(first, first + count):
         bad += 1
         print(f"MISMATCH seed {seed}: {W}x{H} depth {sc.trace_depth} aperture {aperture:.3g}: draws {n} vs {nd}, pixels off by more than 1e-5: {npx}, bit-identical: {same_bits}", flush=True)
     if (seed - first) % 10 == 0: print(f"seed {seed}: {W}x{H}, {nd} draws, bit-identical frames so far {exact} of {frames}", flush=True)
-print("frames", frames, "bit-identical", exact, "mismatches", bad)
+print("frames", frames, "bit-identical", exact, "of which with materials edited after the build", edited, "mismatches", bad)
 sys.exit(1 if bad else 0)
