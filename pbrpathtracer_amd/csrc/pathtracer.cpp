@@ -705,8 +705,16 @@ void PathTracer::Exit() { if (m->ctx) ptk_request_exit(m->ctx); }      // :819-8
 
 // ---- extensions -----------------------------------------------------------------------------------------
 void PathTracer::SetSeed(uint64_t seed) { m->seed = seed; }
-void PathTracer::SetOutGLBuffer(unsigned int gl_buffer) { m->out_gl = gl_buffer; if (gl_buffer) { m->out_img = 0; m->out_dev = 0; } }
-void PathTracer::SetOutDeviceImage(void* device_rgb8) { m->out_dev = device_rgb8; if (device_rgb8) { m->out_img = 0; m->out_gl = 0; } }
+void PathTracer::SetOutGLBuffer(unsigned int gl_buffer)
+{
+    m->out_gl = gl_buffer;
+    if (gl_buffer) { SetOutImage(0); m->out_dev = 0; }                // (a host buffer that was bound is let go at once, as in SetOutImage)
+}
+void PathTracer::SetOutDeviceImage(void* device_rgb8)
+{
+    m->out_dev = device_rgb8;
+    if (device_rgb8) { SetOutImage(0); m->out_gl = 0; }
+}
 void PathTracer::SetDevice(int ordinal) { if (!m->ctx) m->device = ordinal; }
 void PathTracer::SetTile(int rank, int world)
 {

@@ -175,21 +175,21 @@ class PathTracer:
         """out: caller-owned uint8 array of W*H*3 (rows bottom-up), written by every RenderFrame()."""
         if out is not None:
             assert out.dtype == np.uint8 and out.flags.c_contiguous
-        self._out = out
         self.L.pth_set_out_image(self.h, out.ctypes.data if out is not None else None)
+        self._out = out                 # (after the call: the previous buffer - this may be its last reference - is unbound before it is freed)
 
     def SetOutGLBuffer(self, gl_buffer: int):
         """Extension: the 8-bit image goes into an OpenGL buffer object of the current context (0 switches back)."""
+        self.L.pth_set_out_gl_buffer(self.h, int(gl_buffer))
         if gl_buffer:
             self._out = None
-        self.L.pth_set_out_gl_buffer(self.h, int(gl_buffer))
 
     def SetOutDeviceImage(self, device_ptr):
         """Extension: the 8-bit image goes into W*H*3 bytes of this GPU's memory (an address, e.g. a torch uint8 tensor's
         data_ptr(), kept alive by the caller); None switches back."""
+        self.L.pth_set_out_device_image(self.h, C.c_void_p(device_ptr) if device_ptr else None)
         if device_ptr:
             self._out = None
-        self.L.pth_set_out_device_image(self.h, C.c_void_p(device_ptr) if device_ptr else None)
 
     def AllocOutImage(self) -> np.ndarray:
         """A page-locked W*H*3 uint8 hand-off buffer (ptk_host_alloc) for SetOutImage: RenderFrame()'s copy into
