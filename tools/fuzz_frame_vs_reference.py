@@ -4,7 +4,7 @@ OpenMP thread, so that its single mt19937 is consumed in pixel order - against t
 (the incremental row walk, the lens sample), every path, the accumulation and its bottom-up layout.  With --libm (libm's sinf / cosf
 compiled into the oracle) the frames must be BIT-IDENTICAL; without, within 1e-5 relative per pixel except where a path parts ways
 (see fuzz_trace_vs_reference.py).   python3 tools/fuzz_frame_vs_reference.py [--libm] [first_seed] [scenes]
-Round 3: 500 frames with --libm, 499 bit-identical; in the one other (seed 3011) three pixels differ where the reference's BVH loses a hit that its own
+Round 3: 1 100 frames with --libm, 1 097 bit-identical; in the three others (seeds 3011, 10237, 10595) one to three pixels differ where the reference's BVH loses a hit that its own
 IntersectTriangle accepts (its box test is not conservative: DESIGN.md section 2, difference 3) - the reference's answer there depends on its per-run tree."""
 
 import os, sys, tempfile
