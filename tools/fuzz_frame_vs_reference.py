@@ -94,13 +94,17 @@ for seed in range(first, first + count):
     aperture = float(np.float32(S.PTS_FOCAL) / np.float32(sc.camera_f))
     ocam = OB.make_camera(cam9[0:3], cam9[3:6], cam9[6:9], float(proj[0]), float(proj[1]), float(sc.focal_dist), aperture)
     ref.lib.ref_seed(5000 + seed)
-    tape = ref.peek_tape(W * H * 400)
+    nframes = 1 + int(rng.uniform() < 0.3) * int(rng.integers(1, 3))        # sometimes two or three RenderFrame() calls: mTotalImg accumulates (:798-800)
+    tape = ref.peek_tape(W * H * 400 * nframes)
     ref.lib.ref_mark()
-    ref.render(1, threads=4)                    # RenderFrame's own rule leaves ONE worker of four (pathtracer.cpp:768-775): pixel order
+    ref.render(nframes, threads=4)              # RenderFrame's own rule leaves ONE worker of four (pathtracer.cpp:768-775): pixel order
     nd = ref.lib.ref_draws_since_mark(len(tape))
     want = ref.total(W, H)
     if nd < 0: print(f"seed {seed}: more draws than the tape holds, skipped"); continue
-    got, n = o.render_tape(ocam, W, H, sc.trace_depth, tape[: nd + 8])
+    got = np.zeros((H, W, 3), np.float32); n = 0
+    for _ in range(nframes):
+        g1, n1 = o.render_tape(ocam, W, H, sc.trace_depth, tape[n: nd + 8])
+        got = got + g1; n += n1              # (float32 adds in frame order, as mTotalImg += color does)
     o.close()
     frames += 1
     same_bits = np.array_equal(got.view(np.uint32), want.view(np.uint32)) or np.array_equal(got, want, equal_nan=True)
