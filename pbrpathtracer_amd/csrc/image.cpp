@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -1370,7 +1371,9 @@ int decode_pic(const std::vector<unsigned char>& d, int& w, int& h, std::vector<
     const int ww = be16(), hh = be16();
     if (at_eof()) return -1;
     r.skip(8);                                                         // ratio, fields, pad
-    if (ww <= 0 || hh <= 0) return -1;
+    // (stb_image refuses what its allocator could not hold: stbi__mad3sizes_valid(x, y, 4, 0), "too large", stb_image.h:6440 - a
+    // 124-byte file whose header claims 65535 x 65535 would otherwise ask for 17 GB here: ADVICE r03)
+    if (ww <= 0 || hh <= 0 || (unsigned long long)ww * (unsigned long long)hh * 4ull > 0x7fffffffull) return -1;
     rgba.assign((size_t)ww * hh * 4, 0xff);
     struct Packet { int type, channel; } packets[10];
     int num_packets = 0, chained;
@@ -1853,20 +1856,15 @@ const int Image::height() const { return mHeight; }
 unsigned char* Image::data() { return mData; }
 
 // image.cpp:38-61
-void Image::Load(const std::string& filename)
+// every format stbi_load reads, in its probe order, then the reference's reduction of anything over 1024 px
+static bool decode_any(const std::vector<unsigned char>& file, int& w, int& h, std::vector<unsigned char>& rgba)
 {
-    if (mData) { std::free(mData); mData = 0; }
-    mFilename = filename;
-    mWidth = mHeight = 0;
-    std::vector<unsigned char> file, rgba;
-    int w = 0, h = 0;
-    if (!read_file(filename, file)) return;                       // missing file -> mData == 0 -> sampler returns 0
     // probe order of stbi__load_main (stb_image.h:1125-1166): PNG, BMP, GIF, PSD, PIC, JPEG, PNM, HDR, and TGA last (weakest signature)
     bool ok = decode_png(file, w, h, rgba) || decode_bmp(file, w, h, rgba) || decode_gif(file, w, h, rgba);
-    if (!ok) { const int r = decode_psd(file, w, h, rgba); if (r < 0) return; ok = r > 0; }
-    if (!ok) { const int r = decode_pic(file, w, h, rgba); if (r < 0) return; ok = r > 0; }
+    if (!ok) { const int r = decode_psd(file, w, h, rgba); if (r < 0) return false; ok = r > 0; }
+    if (!ok) { const int r = decode_pic(file, w, h, rgba); if (r < 0) return false; ok = r > 0; }
     if (!ok) ok = decode_jpeg(file, w, h, rgba) || decode_pnm(file, w, h, rgba) || decode_hdr(file, w, h, rgba) || decode_tga(file, w, h, rgba);
-    if (!ok) return;
+    if (!ok) return false;
     if (w > 1024 || h > 1024)
     {
         float scale = 1024.f / fmax(w, h);                        // image.cpp:49
@@ -1879,6 +1877,24 @@ void Image::Load(const std::string& filename)
         rgba.swap(small);
         w = nw; h = nh;
     }
+    return true;
+}
+
+void Image::Load(const std::string& filename)
+{
+    if (mData) { std::free(mData); mData = 0; }
+    mFilename = filename;
+    mWidth = mHeight = 0;
+    std::vector<unsigned char> file, rgba;
+    int w = 0, h = 0;
+    // (no exception may cross the C ABI above this class - pth_image_load, Set...TextureForElement: a file whose header passes
+    // every size check and still cannot be allocated leaves the image empty, as stb_image's "outofmem" leaves the reference's)
+    try
+    {
+        if (!read_file(filename, file)) return;                   // missing file -> mData == 0 -> sampler returns 0
+        if (!decode_any(file, w, h, rgba)) return;
+    }
+    catch (const std::exception&) { return; }
     mData = (unsigned char*)std::malloc(rgba.size());
     if (!mData) return;
     std::memcpy(mData, rgba.data(), rgba.size());

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <fstream>
 #include <limits>
+#include <mutex>
 #include <sstream>
 #include <thread>
 
@@ -406,11 +407,16 @@ struct PathTracer::Impl {
     std::vector<Image*> textures;
 
     glm::ivec2 resolution = glm::ivec2(0, 0);
+    // The hand-off target.  The viewer calls SetOutImage from its GUI thread (InitializeFrame, main.cpp:3425-3446) while
+    // PathTracerLoop may be inside RenderFrame() on another (main.cpp:3665-3678): the setters only STORE, under bind_mu, and
+    // RenderFrames() takes one snapshot per call and does all the device-layer work on its own thread.
+    std::mutex bind_mu;
     GLubyte* out_img = 0;
-    GLubyte* bound_img = 0;             // what ptk_bind_out_image holds (bound lazily: binding needs the frame)
-    unsigned out_gl = 0, bound_gl = 0;  // SetOutGLBuffer: an OpenGL buffer object instead of a host buffer
+    GLubyte* bound_img = 0;             // what ptk_bind_out_image was last told (render thread only)
+    unsigned out_gl = 0;                // SetOutGLBuffer: an OpenGL buffer object instead of a host buffer (registered by the setter itself)
     void* out_dev = 0; void* bound_dev = 0;   // SetOutDeviceImage: a device buffer instead of a host buffer
-    bool bind_dirty = true;             // the library may have dropped the binding: call ptk_bind_out_image again, whatever the pointer
+    bool bind_dirty = true;             // the library may have dropped the binding: say again what is bound, whatever the pointer
+    std::mutex render_mu;               // held by RenderFrames() for its duration and by SetOutGLBuffer while it talks to the device layer
     int max_depth = 3;                                     // pathtracer.cpp:15
 
     float cam_pos[3] = { 0, 0, 0 }, cam_dir[3] = { 0, 0, 1 }, cam_up[3] = { 0, 1, 0 };   // :17-18
@@ -590,16 +596,15 @@ void PathTracer::ClearScene()                                           // :281-
     m->have_resolution = false;                                        // mTotalImg is freed (:292-294)
 }
 
-// :297-300.  The buffer the device layer holds page-locked (ptk_bind_out_image) is let go HERE, not at the next RenderFrame():
-// the viewer frees texData and allocates the next one right around this call (main.cpp:3433-3445), and memory that is freed
-// while still registered with the runtime poisons whatever the allocator puts there next (found by tools/soak_api.py: a later
-// scene upload staged its triangles in such a range and the copy to the device was refused).
+// :297-300: a pointer store, as in the reference - safe from the viewer's GUI thread while RenderFrame() runs on another.  The
+// buffer stays the caller's in every respect: ordinary memory (`new GLubyte[w * h * 3]`, main.cpp:3435) is never page-locked or
+// otherwise registered with the runtime (the viewer deletes texData BEFORE it hands over the next buffer, main.cpp:3433-3445, and
+// at exit without telling the tracer, :3622); RenderFrame() copies the resolved frame into it.  Memory from ptk_host_alloc is
+// written by the accumulate kernel directly (no copy); free such a buffer only after the RenderFrame() in flight has returned.
 void PathTracer::SetOutImage(GLubyte* out)
 {
-    // (even when the new pointer EQUALS the old one: a buffer freed and allocated again at the same address - mmap'd blocks of a
-    // few megabytes do that - has other pages behind it than the ones that were locked)
-    if (m->bound_img && m->ctx) { m->note(ptk_bind_out_image(m->ctx, 0)); m->bound_img = 0; }
-    m->bind_dirty = true;
+    std::lock_guard<std::mutex> g(m->bind_mu);
+    m->bind_dirty = true;               // (even for the same pointer: a block freed and allocated again at the same address is another buffer)
     m->out_img = out;
     if (out) { m->out_gl = 0; m->out_dev = 0; }
 }
@@ -647,6 +652,7 @@ void PathTracer::RenderFrames(int count)
     if (!m->scene_uploaded && m->built_once && !m->triangles.empty())
         m->error = "geometry changed after BuildBVH(): call BuildBVH() again before RenderFrame()";   // (the reference would chase dangling pointers)
     if (!m->scene_uploaded || !m->have_resolution || !m->ensure_ctx()) return;
+    std::lock_guard<std::mutex> render_guard(m->render_mu);
     int rc;
     if (m->materials_dirty || m->textures_dirty)
     {
@@ -676,16 +682,24 @@ void PathTracer::RenderFrames(int count)
         m->note(rc);
         if (rc != PTK_OK) return;
         m->frame_dirty = false;
+        std::lock_guard<std::mutex> g(m->bind_mu);
         m->bind_dirty = true;                                           // (a new resolution unbinds the hand-off buffer: say again what is bound)
     }
-    if (m->bind_dirty || m->out_img != m->bound_img || m->out_gl != m->bound_gl || m->out_dev != m->bound_dev)
+    GLubyte* out_img; unsigned out_gl; void* out_dev; bool rebind;
     {
+        // one snapshot of the hand-off target per call (the setters may run on another thread)
+        std::lock_guard<std::mutex> g(m->bind_mu);
+        out_img = m->out_img; out_gl = m->out_gl; out_dev = m->out_dev;
+        rebind = m->bind_dirty || out_img != m->bound_img || out_dev != m->bound_dev;
         m->bind_dirty = false;
-        // SetOutImage (:297-300): the 8-bit resolve goes straight into the caller's buffer from now on
-        if (m->out_gl) m->note(ptk_bind_gl_buffer(m->ctx, m->out_gl));
-        else if (m->out_dev) m->note(ptk_bind_out_device(m->ctx, m->out_dev));
-        else m->note(ptk_bind_out_image(m->ctx, m->out_img));
-        m->bound_img = m->out_img; m->bound_gl = m->out_gl; m->bound_dev = m->out_dev;
+    }
+    if (rebind && !out_gl)
+    {
+        // SetOutImage (:297-300): a buffer the GPU can write (ptk_host_alloc) receives the 8-bit resolve straight from the
+        // accumulate kernel from now on; ordinary memory is not bound, the frame is copied into it below
+        if (out_dev) m->note(ptk_bind_out_device(m->ctx, out_dev));
+        else m->note(ptk_bind_out_image(m->ctx, out_img));
+        m->bound_img = out_img; m->bound_dev = out_dev;
     }
     if (m->need_reset)                                                 // :745-751
     {
@@ -697,23 +711,39 @@ void PathTracer::RenderFrames(int count)
     rc = ptk_render(m->ctx, first, (uint32_t)count, m->seed);         // mSamples += count (:753)
     m->note(rc);
     m->samples = ptk_samples(m->ctx);
-    if (rc == PTK_OK && m->out_img) m->note(ptk_resolve_rgb8(m->ctx, m->out_img));   // :802-812 into the caller's buffer
-    else if (rc == PTK_OK && (m->out_gl || m->out_dev)) m->note(ptk_synchronize(m->ctx));   // RenderFrame() returns with the frame in the OpenGL / device buffer
+    if (rc == PTK_OK && out_img) m->note(ptk_resolve_rgb8(m->ctx, out_img));   // :802-812 into the caller's buffer
+    else if (rc == PTK_OK && (out_gl || out_dev)) m->note(ptk_synchronize(m->ctx));   // RenderFrame() returns with the frame in the OpenGL / device buffer
 }
 
 void PathTracer::Exit() { if (m->ctx) ptk_request_exit(m->ctx); }      // :819-822
 
 // ---- extensions -----------------------------------------------------------------------------------------
 void PathTracer::SetSeed(uint64_t seed) { m->seed = seed; }
+// EXPERIMENTAL (built, its refusal tested, never executed: the GPU boxes are headless).  Registration talks to the OpenGL driver
+// through the CALLING thread's current context, so it happens here, in the setter the viewer's GUI thread calls - not inside
+// RenderFrame(), which the viewer runs on a thread without a context (PathTracerLoop, main.cpp:3665-3678).  The setter waits for a
+// RenderFrame() in flight.  RenderFrame() maps the buffer on its stream before the first pass and unmaps it behind the
+// accumulate kernel; the GUI thread may read the buffer (glTexSubImage2D from GL_PIXEL_UNPACK_BUFFER) only BETWEEN frames, i.e.
+// it sequences itself with the render thread exactly as it must for texData.
 void PathTracer::SetOutGLBuffer(unsigned int gl_buffer)
 {
-    m->out_gl = gl_buffer;
-    if (gl_buffer) { SetOutImage(0); m->out_dev = 0; }                // (a host buffer that was bound is let go at once, as in SetOutImage)
+    std::lock_guard<std::mutex> render_guard(m->render_mu);
+    {
+        std::lock_guard<std::mutex> g(m->bind_mu);
+        m->out_gl = gl_buffer;
+        if (gl_buffer) { m->out_img = 0; m->out_dev = 0; }
+        m->bind_dirty = true;
+    }
+    if (!m->ensure_ctx()) return;
+    m->note(ptk_bind_gl_buffer(m->ctx, gl_buffer));                   // (0: lets a registered buffer go, on the thread that owns the context)
+    m->bound_img = 0; m->bound_dev = 0;
 }
 void PathTracer::SetOutDeviceImage(void* device_rgb8)
 {
+    std::lock_guard<std::mutex> g(m->bind_mu);
     m->out_dev = device_rgb8;
-    if (device_rgb8) { SetOutImage(0); m->out_gl = 0; }
+    m->bind_dirty = true;
+    if (device_rgb8) { m->out_img = 0; m->out_gl = 0; }
 }
 void PathTracer::SetDevice(int ordinal) { if (!m->ctx) m->device = ordinal; }
 void PathTracer::SetTile(int rank, int world)

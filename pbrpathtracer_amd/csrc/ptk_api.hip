@@ -38,6 +38,9 @@ struct ptk_ctx {
     uint32_t* d_texels = nullptr;
     int num_nodes = 0, num_tris = 0, num_lights = 0, bvh_depth = 0, bvh_stack = 0, num_leaf_tris = 0;
     float scene_bound = 0.0f;           // 3.1 x (1.01 x the largest |vertex coordinate| + 1e-3): RenderParams::scene_bound
+    float scene_lo[3] = { 0, 0, 0 }, scene_hi[3] = { 0, 0, 0 };     // the vertices' bounding box
+    int opt_lens_cull = 1;              // uncached cameras: pixels whose whole bundle of lens rays misses that box are never traced
+    unsigned long long view_generation = 0;      // bumped whenever camera, frame or scene change what an uncached pixel can see
     bool have_scene = false;
     double upload_ms[4] = { 0, 0, 0, 0 };       // last ptk_upload_scene: BVH build, record packing, device copies, total
     // host copies kept for ptk_update_materials: what was uploaded, the texture index map, the light records
@@ -115,6 +118,7 @@ struct ptk_ctx {
     bool inputs_dirty = true;                    // scene / camera tables were (re)written on the context's stream since ev_inputs
     unsigned pass_counter = 0;
     int opt_overlap = 1;
+    int opt_register_out = 0;                    // 1: ptk_bind_out_image page-locks a pageable caller buffer in place (round 3's default; the caller must unbind before freeing)
     int opt_contract = 0;                        // 0: bit-exact kernels; 1: -ffp-contract=fast build; 2: ... with 1-ulp hardware rcp / sqrt
     int opt_chunk = 0;                           // samples per work item; 0 = automatic (8, or 4 for small shares)
     int num_cus = 256;
@@ -241,6 +245,7 @@ int ensure_primary(ptk_ctx* c)
     launch_primary(pp, c->stream);
     HIPCHK(c, hipGetLastError());
     c->primary_dirty = false;
+    c->view_generation++;
     c->primary_hit_dirty = true;
     c->inputs_dirty = true;
     return PTK_OK;
@@ -272,6 +277,8 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     p.rgb8_host = nullptr; p.rgb8_host_full = 1;
     p.accum = accum_ptr(c); p.rgb8 = c->d_rgb8; p.exit_flag = c->d_exit; p.exit_gen = c->render_gen.load(); p.stats = c->d_stats;
     p.num_nodes = c->num_nodes; p.num_lights = c->num_lights; p.scene_bound = c->scene_bound;
+    for (int a = 0; a < 3; a++) { p.scene_lo[a] = c->scene_lo[a]; p.scene_hi[a] = c->scene_hi[a]; }
+    p.lens_cull = c->opt_lens_cull;
     p.flat_count = (c->opt_flat && c->num_tris <= 16 && c->d_flat_tris) ? c->num_tris : 0;
     p.flat_shade_w = c->opt_flat_shade_w; p.flat_gen_w = c->opt_flat_gen_w;
     p.width = c->width; p.height = c->height; p.max_depth = c->max_depth;
@@ -285,12 +292,17 @@ void fill_params(ptk_ctx* c, RenderParams& p, uint32_t first, uint32_t spp, uint
     p.resolve_samples = (float)(first + spp);
 }
 
-void unbind_out_image(ptk_ctx* c)
+// keep_gl: a new resolution lets host and device buffers go (the caller reallocates them) but keeps an OpenGL buffer object
+// registered - unregistering talks to the OpenGL driver and belongs to the thread that owns the context (ptk_bind_gl_buffer);
+// the buffer's size is checked each time it is mapped
+void unbind_out_image(ptk_ctx* c, bool keep_gl = false)
 {
     if (c->out_registered && c->out_host) { (void)hipHostUnregister(c->out_host); (void)hipGetLastError(); }
-    if (c->gl_res) { (void)hipGraphicsUnregisterResource(c->gl_res); (void)hipGetLastError(); }
     c->out_host = nullptr; c->out_host_dev = nullptr; c->out_registered = false; c->out_full_next = true;
-    c->out_device = nullptr; c->gl_res = nullptr; c->gl_buffer = 0;
+    c->out_device = nullptr;
+    if (keep_gl) return;
+    if (c->gl_res) { (void)hipGraphicsUnregisterResource(c->gl_res); (void)hipGetLastError(); }
+    c->gl_res = nullptr; c->gl_buffer = 0;
 }
 
 // An OpenGL buffer object is HIP's for the length of a render only: mapped before the first pass, unmapped (on the render
@@ -374,7 +386,9 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
             c->live_capacity = subtiles;
             c->live_key.rank = -1;
         }
-        const ptk_ctx::LiveKey key = { c->width, c->height, c->rank, c->world, p.primary_hit ? 1 : 0, p.primary_hit ? c->hit_generation : 0ull };
+        // (uncached cameras: the mask holds the pixels whose lens rays can reach the scene at all - it follows camera, frame and scene)
+        const ptk_ctx::LiveKey key = { c->width, c->height, c->rank, c->world, p.primary_hit ? 1 : (p.lens_cull ? 2 : 0),
+                                       p.primary_hit ? c->hit_generation : (p.lens_cull ? c->view_generation : 0ull) };
         const ptk_ctx::LiveKey& o = c->live_key;
         if (key.width != o.width || key.height != o.height || key.rank != o.rank || key.world != o.world || key.cached != o.cached ||
             key.generation != o.generation)
@@ -394,30 +408,78 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
     int chunk_opt = c->opt_chunk;
     if (chunk_opt <= 0)
         chunk_opt = (double)spp * (double)tiles * 4.0 / 8.0 >= 49152.0 ? 8 : 4;
-    uint32_t max_pass = (uint32_t)std::max<size_t>(1, c->opt_pass_bytes / per_sample);
+    // (a bound hand-off buffer means the caller waits for every frame: nothing to overlap, and one stream is two event
+    // hops per frame less)
+    const bool overlap = c->opt_overlap != 0 && c->trace_stream[0] != nullptr && !handoff;
+    // The pass size: what the sample-buffer budget allows - and what the device can actually give.  When an allocation of that
+    // size fails (memory shared with the caller's framework, a huge scene, a 144-megapixel frame) the pass is halved and tried
+    // again instead of failing the render: more passes, the same image (chunk boundaries never change a bit).
+    size_t budget = c->opt_pass_bytes;
+    {
+        const size_t have = overlap ? std::min(c->samples_bytes2[0], c->samples_bytes2[1]) : c->samples_bytes;
+        const size_t want = std::min(budget, per_sample * ((size_t)spp + (size_t)chunk_opt));      // (what this render asks for at most)
+        size_t free_b = 0, total_b = 0;
+        if (want > have)             // (only a render that has to allocate asks the driver: the interactive loop never does)
+        {
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            {
+                // the buffers still to be allocated may take at most half of what is free now (there are two of them when overlapping)
+                const size_t share = free_b / (overlap ? 4 : 2);
+                if (budget > std::max(share, have)) budget = std::max(share, have);
+            }
+            else (void)hipGetLastError();
+        }
+    }
+    uint32_t max_pass = (uint32_t)std::max<size_t>(1, budget / per_sample);
     if (max_pass > (uint32_t)chunk_opt) max_pass -= max_pass % (uint32_t)chunk_opt;
+    // grows *buf to `need` bytes; false (nothing allocated, *bytes = 0) when the device refuses
+    auto grow = [&](float4*& buf, size_t& bytes, size_t need) -> bool {
+        dfree(buf); bytes = 0;
+        if (hipMalloc(&buf, need) != hipSuccess) { (void)hipGetLastError(); buf = nullptr; return false; }
+        bytes = need;
+        return true;
+    };
     uint32_t done = 0;
     while (done < spp)
     {
-        const uint32_t n = std::min(spp - done, max_pass);
-        const int chunk = (int)std::min<uint32_t>(n, (uint32_t)chunk_opt);
-        const int num_chunks = (int)((n + chunk - 1) / chunk);
-        const size_t need = per_sample * (size_t)chunk * num_chunks;
-        // (a bound hand-off buffer means the caller waits for every frame: nothing to overlap, and one stream is two event
-        // hops per frame less)
-        const bool overlap = c->opt_overlap != 0 && c->trace_stream[0] != nullptr && !handoff;
+        uint32_t n = std::min(spp - done, max_pass);
+        int chunk = (int)std::min<uint32_t>(n, (uint32_t)chunk_opt);
+        int num_chunks = (int)((n + chunk - 1) / chunk);
+        size_t need = per_sample * (size_t)chunk * num_chunks;
         const int b = (int)(c->pass_counter & 1u);
         hipStream_t tstream = overlap ? c->trace_stream[b] : c->stream;
+        for (;;)
+        {
+            bool ok = true;
+            if (overlap)
+            {
+                // BOTH buffers are brought to size together: the second one would otherwise be allocated - a blocking call of tens of
+                // milliseconds for gigabytes - in the middle of the second render (BENCH_r03: C3's first timed steps)
+                if (need > c->samples_bytes2[0] || need > c->samples_bytes2[1])
+                {
+                    HIPCHK(c, hipStreamSynchronize(c->trace_stream[0]));
+                    HIPCHK(c, hipStreamSynchronize(c->trace_stream[1]));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    for (int k = 0; k < 2 && ok; k++)
+                        if (need > c->samples_bytes2[k]) ok = grow(c->d_samples2[k], c->samples_bytes2[k], need);
+                }
+            }
+            else if (need > c->samples_bytes)
+            {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                ok = grow(c->d_samples, c->samples_bytes, need);
+            }
+            if (ok) break;
+            if (n <= (uint32_t)chunk && chunk <= 1) return fail(c, PTK_ERR_HIP, "hipMalloc: no memory for the sample buffer of even one sample per pixel");
+            // halve the pass (whole chunks while there are several, then the chunk itself) and try again
+            if (n > (uint32_t)chunk) { n = std::max<uint32_t>((uint32_t)chunk, (n / 2) / (uint32_t)chunk * (uint32_t)chunk); }
+            else { chunk = std::max(1, chunk / 2); n = (uint32_t)chunk; }
+            max_pass = n;
+            num_chunks = (int)((n + chunk - 1) / chunk);
+            need = per_sample * (size_t)chunk * num_chunks;
+        }
         if (overlap)
         {
-            if (need > c->samples_bytes2[b])
-            {
-                HIPCHK(c, hipStreamSynchronize(c->trace_stream[b]));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                dfree(c->d_samples2[b]); c->samples_bytes2[b] = 0;
-                HIPCHK(c, hipMalloc(&c->d_samples2[b], need));
-                c->samples_bytes2[b] = need;
-            }
             p.samples = c->d_samples2[b];
             if (c->inputs_dirty || !c->inputs_recorded)
             {
@@ -427,17 +489,7 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
             HIPCHK(c, hipStreamWaitEvent(tstream, c->ev_inputs, 0));
             if (c->acc_pending[b]) HIPCHK(c, hipStreamWaitEvent(tstream, c->ev_acc_done[b], 0));   // buffer b was last read by pass k-2's accumulate
         }
-        else
-        {
-            if (need > c->samples_bytes)
-            {
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                dfree(c->d_samples); c->samples_bytes = 0;
-                HIPCHK(c, hipMalloc(&c->d_samples, need));
-                c->samples_bytes = need;
-            }
-            p.samples = c->d_samples;
-        }
+        else p.samples = c->d_samples;
         p.pool = nullptr; p.pool_slots = 0; p.pool_blocks = 0; p.fetch_thr = c->opt_fetch_thr; p.switch_thr = c->opt_switch_thr;
         if (c->opt_pool >= 64 && p.flat_count == 0)
         {
@@ -623,10 +675,14 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     // the kernels' exact short reciprocal (ptk_kernels.hip rcp_ieee) covers determinants and lengths up to 2^126: coordinates
     // must stay below 2^61 in magnitude (the reference's own float arithmetic is long meaningless out there)
     float vmax = 0.0f;
+    float vlo[3] = { INFINITY, INFINITY, INFINITY }, vhi[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (size_t i = 0; i < (size_t)n * 9; i++)
     {
-        if (!(std::fabs(s->verts[i]) < 2.305843e18f)) return fail(c, PTK_ERR_LIMIT, "vertex coordinate is not finite or exceeds 2^61");
-        vmax = std::max(vmax, std::fabs(s->verts[i]));
+        const float v = s->verts[i];
+        if (!(std::fabs(v) < 2.305843e18f)) return fail(c, PTK_ERR_LIMIT, "vertex coordinate is not finite or exceeds 2^61");
+        vmax = std::max(vmax, std::fabs(v));
+        const int a = (int)(i % 3);
+        vlo[a] = std::min(vlo[a], v); vhi[a] = std::max(vhi[a], v);
     }
     // (node origins lie within the triangle boxes padded by 1e-5 x their extent plus the degenerate-box epsilon)
     const float scene_bound = 3.1f * (1.01f * vmax + 1e-3f);
@@ -811,6 +867,8 @@ int ptk_upload_scene(ptk_ctx* c, const ptk_scene_desc* s)
     HIPCHK(c, up((void**)&c->d_texels, texels.data(), texels.size() * 4));
     c->num_nodes = bvh.num_nodes; c->num_tris = n; c->num_lights = s->num_lights; c->bvh_depth = bvh.depth; c->bvh_stack = bvh.stack_need;
     c->scene_bound = scene_bound;
+    for (int a = 0; a < 3; a++) { c->scene_lo[a] = n > 0 ? vlo[a] : 0.0f; c->scene_hi[a] = n > 0 ? vhi[a] : 0.0f; }
+    c->view_generation++;
     c->scene_has_opacity = false;
     for (int32_t i = 0; i < n; i++)
         if (s->materials[s->material[i]].tex[5] >= 0) { c->scene_has_opacity = true; break; }
@@ -899,7 +957,7 @@ int ptk_set_frame(ptk_ctx* c, int width, int height, int max_depth)
         HIPCHK(c, hipMalloc(&c->d_rgb8, px * 3));
         c->width = width; c->height = height;
         c->d_accum_bound = nullptr;
-        unbind_out_image(c);                     // another resolution: the caller's buffer has another size (main.cpp:3425-3446)
+        unbind_out_image(c, true);               // another resolution: the caller's buffer has another size (main.cpp:3425-3446)
         HIPCHK(c, hipMemsetAsync(c->d_accum, 0, px * 3 * sizeof(float), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_rgb8, 0, px * 3, c->stream));
         c->samples = 0;
@@ -911,6 +969,7 @@ int ptk_set_frame(ptk_ctx* c, int width, int height, int max_depth)
 int ptk_set_tile(ptk_ctx* c, int rank, int world)
 {
     if (!c || world < 1 || rank < 0 || rank >= world) return PTK_ERR_BAD_ARG;
+    if (rank != c->rank || world != c->world) c->out_full_next = true;      // other tiles: a bound hand-off buffer is rewritten whole
     c->rank = rank; c->world = world;
     return PTK_OK;
 }
@@ -994,26 +1053,40 @@ int ptk_bind_out_image(ptk_ctx* c, uint8_t* host_out)
 {
     if (!c) return PTK_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    if (host_out == c->out_host && !c->out_device && !c->gl_res) return PTK_OK;
+    // (the same buffer again: nothing to do - unless this context page-locked it, see below: a block freed and allocated again at
+    // the same address has other pages behind it than the ones that were locked)
+    if (host_out == c->out_host && !c->out_registered && !c->out_device && !c->gl_res) return PTK_OK;
     if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));      // nothing may still be writing into the old buffer
     unbind_out_image(c);
     if (!host_out) return PTK_OK;
     if (c->width <= 0 || !c->d_rgb8) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
-    c->out_host = host_out;
-    std::memset(host_out, 0, (size_t)c->width * c->height * 3);     // pixels that are black for every sample are written once at most
+    // Zero-copy needs memory the GPU can write.  A buffer that already IS such memory - ptk_host_alloc, or anything the caller
+    // page-locked and mapped itself - is used as it stands.  FOREIGN pageable memory (the viewer's `new GLubyte[w * h * 3]`,
+    // main.cpp:3435) is left alone by default: the reference's caller deletes texData BEFORE it hands over the next buffer
+    // (InitializeFrame, main.cpp:3433-3445) and at exit without a word to the tracer (OnExit, :3622), and memory freed while
+    // still registered with the runtime poisons what the allocator puts there next (tools/soak_api.py, round 3).
+    // Such a buffer is simply not bound: ptk_resolve_rgb8 copies the frame into it, which is always correct.
+    // ptk_set_option("register_out_image", 1) opts in to page-locking it in place (hipHostRegister) for callers that promise
+    // to unbind - ptk_bind_out_image(ctx, NULL) - BEFORE they free it.
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, host_out, 0) == hipSuccess && dev) c->out_host_dev = (uint8_t*)dev;       // ptk_host_alloc / already page-locked
     else
     {
         (void)hipGetLastError();
-        const size_t bytes = (size_t)c->width * c->height * 3;
-        if (hipHostRegister(host_out, bytes, hipHostRegisterMapped) == hipSuccess)
+        if (c->opt_register_out)
         {
-            if (hipHostGetDevicePointer(&dev, host_out, 0) == hipSuccess && dev) { c->out_host_dev = (uint8_t*)dev; c->out_registered = true; }
-            else (void)hipHostUnregister(host_out);
+            const size_t bytes = (size_t)c->width * c->height * 3;
+            if (hipHostRegister(host_out, bytes, hipHostRegisterMapped) == hipSuccess)
+            {
+                if (hipHostGetDevicePointer(&dev, host_out, 0) == hipSuccess && dev) { c->out_host_dev = (uint8_t*)dev; c->out_registered = true; }
+                else (void)hipHostUnregister(host_out);
+            }
+            (void)hipGetLastError();             // not lockable: ptk_resolve_rgb8 keeps copying
         }
-        (void)hipGetLastError();                 // not lockable: ptk_resolve_rgb8 keeps copying, which is always correct
     }
+    if (!c->out_host_dev) return PTK_OK;         // not bound (see above)
+    c->out_host = host_out;
+    std::memset(host_out, 0, (size_t)c->width * c->height * 3);     // pixels that are black for every sample are written once at most
     c->out_full_next = true;
     return PTK_OK;
 }
@@ -1063,7 +1136,7 @@ int ptk_bind_gl_buffer(ptk_ctx* c, unsigned int gl_buffer)
     if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
     unbind_out_image(c);
     if (gl_buffer == 0) return PTK_OK;
-    if (c->width <= 0 || !c->d_rgb8) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    // (no frame needed yet: the buffer's size is checked against the frame each time it is mapped, run_passes)
     // Registration talks to the OpenGL driver through the calling thread's CURRENT context (the viewer's: main.cpp creates it
     // before the path tracer renders anything).  The library does not link OpenGL: the process that calls this has it loaded,
     // and a process without a current context gets an error here instead of a crash inside the runtime.
@@ -1178,6 +1251,7 @@ int ptk_bind_accum(ptk_ctx* c, void* dev_ptr)
 {
     if (!c) return PTK_ERR_BAD_ARG;
     if (!c->d_accum) return fail(c, PTK_ERR_BAD_ARG, "ptk_set_frame has not been called");
+    if ((float*)dev_ptr != c->d_accum_bound) c->out_full_next = true;       // another accumulator: pixels that were skipped as "always black" may hold light there
     c->d_accum_bound = (float*)dev_ptr;
     return PTK_OK;
 }
@@ -1458,6 +1532,18 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     if (!std::strcmp(name, "overlap"))
     {
         c->opt_overlap = value != 0.0 ? 1 : 0;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "lens_cull"))
+    {
+        // 0: uncached cameras trace every pixel of the frame (the cull is exact: same image either way; tests / A-B only)
+        c->opt_lens_cull = value != 0.0 ? 1 : 0;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "register_out_image"))
+    {
+        // 1: ptk_bind_out_image page-locks a pageable caller buffer in place (zero-copy hand-off; the caller unbinds before freeing it)
+        c->opt_register_out = value != 0.0 ? 1 : 0;
         return PTK_OK;
     }
     if (!std::strcmp(name, "bvh_leaf_max") || !std::strcmp(name, "bvh_trav_cost") || !std::strcmp(name, "bvh_verbose"))

@@ -90,6 +90,8 @@ struct RenderParams {
     unsigned long long* stats;  // 7 counters (STATS variant only)
     int num_nodes, num_lights;
     float scene_bound;          // 3.1 x the largest |coordinate| of the scene's padded bounds: the per-ray slack of the slab tests (Walk::begin)
+    float scene_lo[3], scene_hi[3];   // the vertices' bounding box (live_mask_kernel: pixels none of whose camera rays can reach it are never traced)
+    int lens_cull;              // 1: uncached cameras (thin lens, opacity textures) cull such pixels from the live mask
     int flat_shade_w, flat_gen_w; // FLAT block-choice weights (eighths) of the shade / camera-ray blocks vs the triangle pass
     int flat_count;             // > 0: tiny scene, test all flat_count triangle records per ray without a BVH walk
     int width, height, max_depth;

@@ -134,6 +134,9 @@ __device__ __forceinline__ float rcp_ieee_any(float a)
 #ifndef PTK_NODE_PREFETCH
 #define PTK_NODE_PREFETCH 1
 #endif
+#ifndef PTK_TRI_PER_EXEC
+#define PTK_TRI_PER_EXEC 2          // triangles one execution of walk_step's (voted) triangle arm tests per lane
+#endif
 #ifndef PTK_FUSED_START
 #define PTK_FUSED_START 1
 #endif
@@ -499,6 +502,38 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
     const float4 q0 = here.q0, q1 = here.q1, q2 = here.q2, q3 = here.q3;
     asm volatile("" ::: "memory");
 #endif
+    const bool node_was = W.node >= 0;
+#if PTK_TRI_PER_EXEC == 2
+    if (run_tri_arm && W.tri_left > 0)                    // ---- arm A: up to TWO triangles
+    {
+        // The second triangle: the pending leaf's next one, or - the pending leaf has only this one left and the lane is BLOCKED
+        // on a second leaf (W.node holds it: the one-leaf queue was busy) - the first triangle of that leaf, whose remainder then
+        // becomes the pending leaf while the lane pops its next node.  Both records are requested together and tested one after
+        // the other: the same tri_test calls in the same order as one per execution, so results cannot differ.  Leaves hold
+        // 1.1-1.5 triangles on average, so what this buys is mostly the blocked leaf - its lane walks on an iteration earlier -
+        // and a triangle arm that is voted 44 % less often (round 4: C4 +2 %, C5 +4 %, C3 +4 %; three or four per execution,
+        // and the pair in packed f32, measured slower: DESIGN 12).
+        const bool two = W.tri_left >= 2;
+        const bool blocked = !two & (W.node < 0) & (W.node != NODE_EXIT);
+        const int code = ~W.node;
+        const int iA = W.tri_next, iB = two ? iA + 1 : (blocked ? (code >> 3) : iA);
+        const float4* tpa = (const float4*)((const char*)P.tris + (uint32_t)iA * (uint32_t)(TRI_F4 * 16));
+        const float4* tpb = (const float4*)((const char*)P.tris + (uint32_t)iB * (uint32_t)(TRI_F4 * 16));
+        float4 a0 = ldg4(tpa), a1 = ldg4(tpa + 1), a2 = ldg4(tpa + 2);
+        float4 b0 = ldg4(tpb), b1 = ldg4(tpb + 1), b2 = ldg4(tpb + 2);
+        bool stop = tri_test<STATS>(P, W, a0, a1, a2, rng, ray, cnt);
+        if ((two | blocked) && !stop) stop = tri_test<STATS>(P, W, b0, b1, b2, rng, ray, cnt);
+        if (blocked)
+        {
+            W.tri_next = (code >> 3) + 1; W.tri_left = code & 7;
+            W.node = W.template pop<STRIDE>(stack);
+        }
+        else { W.tri_next = iA + (two ? 2 : 1); W.tri_left -= two ? 2 : 1; }
+        W.top = stop ? stack : W.top;                     // an occluder decides a shadow ray: drop everything
+        W.tri_left = stop ? 0 : W.tri_left;
+        W.node = stop ? NODE_EXIT : W.node;
+    }
+#else
     if (run_tri_arm && W.tri_left > 0)                    // ---- arm A: one triangle
     {
         const float4* tp = (const float4*)((const char*)P.tris + (uint32_t)W.tri_next * (uint32_t)(TRI_F4 * 16));
@@ -509,7 +544,8 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
         W.tri_left = stop ? 0 : W.tri_left;
         W.node = stop ? NODE_EXIT : W.node;
     }
-    if (W.node >= 0)                                      // ---- arm B: one 4-wide interior node
+#endif
+    if (node_was && W.node >= 0)                          // ---- arm B: one 4-wide interior node (its record is `here`; a node popped by arm A waits a step)
     {
 #if !PTK_NODE_PREFETCH
         const float4* np = P.nodes + (size_t)W.node * NODE_F4;
@@ -1740,7 +1776,9 @@ __global__ __launch_bounds__(PTK_BLOCK) void accumulate_kernel(const RenderParam
     const size_t accidx = ((size_t)(P.height - 1 - py) * P.width + px) * 3;   // bottom-up (pathtracer.cpp:796)
     v3 acc = V(P.accum[accidx], P.accum[accidx + 1], P.accum[accidx + 2]);
     const size_t subtile = (size_t)owned * 4 + quad;
-    const bool black = P.primary_hit && __float_as_int(P.primary_hit[(size_t)py * P.width + px].x) == PTK_NOHIT;
+    // (a pixel that is not in its quadrant's live mask - cached camera ray misses, or no lens ray reaches the scene - was not
+    // traced: nothing was stored for it and it receives nothing)
+    const bool black = ((P.live_mask[subtile] >> lane) & 1ull) == 0ull;
     if (!black)
     {
         // the samples of one pixel are a strided array (chunk after chunk of its quadrant's items): sample s sits at
@@ -1936,8 +1974,49 @@ __global__ void queue_init_kernel(unsigned* block, const QueueGeometry geo, cons
 }
 
 #if !PTK_CONTRACT
+// Uncached cameras (thin lens; pinhole with opacity textures): can ANY camera ray of this pixel reach the scene?  Every lens ray
+// of a pixel starts inside the aperture square around the camera position and passes through the pixel's focal point
+// (pathtracer.cpp:785-791; the camera-ray block of trace_kernel): origin o = cam + x right + y up with |x|, |y| <= aperture,
+// direction parallel to F - o.  Per axis that is o_k in [cam_k - h_k, cam_k + h_k], d_k in [F_k - cam_k - h_k, F_k - cam_k + h_k]
+// with h_k = aperture (|right_k| + |up_k|); taking the two intervals as independent (a superset of the bundle), the ray
+// parameters t >= 0 at which SOME such ray is inside the scene's bounding box on axis k form an interval given by two linear
+// inequalities; the pixel is dead - black for every sample, never traced, nothing stored - when the three intervals have no
+// common point.  Conservative by construction and by margin: the box is padded by 1e-4 of the scene's size and of the camera's
+// distance (Moeller-Trumbore accepts nothing measurably outside a triangle, and every triangle lies in the box), the intervals by
+// the float rounding of o, F and the normalised direction; evaluated in double, once per camera / frame / scene change.
+// Exact: bit-identical images with the cull on and off (tests/test_gpu_host_api.py::test_lens_cull_is_exact).
+__device__ bool lens_rays_may_reach_scene(const RenderParams& P, const float4 d0)
+{
+    double ext = 0.0, far_ = 0.0;
+    for (int k = 0; k < 3; k++)
+    {
+        ext = fmax(ext, (double)P.scene_hi[k] - (double)P.scene_lo[k]);
+        far_ = fmax(far_, fmax(fabs((double)P.scene_lo[k] - (double)P.cam_pos[k]), fabs((double)P.scene_hi[k] - (double)P.cam_pos[k])));
+    }
+    const double pad = 1e-4 * (ext + far_) + 1e-5;
+    const double ap = fabs((double)P.aperture) * 1.0001;
+    const float dir0[3] = { d0.x, d0.y, d0.z };
+    double tlo = 0.0, thi = 1e300;
+    bool feasible = true;
+    for (int k = 0; k < 3; k++)
+    {
+        const float Ff = P.cam_pos[k] + dir0[k] * P.focal_dist;            // the focal point as the camera-ray block computes it
+        const double oc = (double)P.cam_pos[k], F = (double)Ff;
+        const double h = ap * (fabs((double)P.cam_right[k]) + fabs((double)P.cam_up[k])) + 1e-6 * fabs(oc);
+        const double dc = F - oc, hd = h + 1e-6 * (fabs(F) + fabs(oc) + fabs(dc));
+        const double lo = (double)P.scene_lo[k] - pad, hi = (double)P.scene_hi[k] + pad;
+        // the smallest coordinate any ray of the bundle has at parameter t must not exceed hi, the largest not fall short of lo
+        const double a1 = (oc - h) - hi, b1 = dc - hd;                     // a1 + t b1 <= 0
+        const double a2 = lo - (oc + h), b2 = -(dc + hd);                  // a2 + t b2 <= 0
+        if (b1 > 0.0) thi = fmin(thi, -a1 / b1); else if (b1 < 0.0) tlo = fmax(tlo, -a1 / b1); else if (a1 > 0.0) feasible = false;
+        if (b2 > 0.0) thi = fmin(thi, -a2 / b2); else if (b2 < 0.0) tlo = fmax(tlo, -a2 / b2); else if (a2 > 0.0) feasible = false;
+    }
+    return feasible && tlo <= thi * (1.0 + 1e-9) + 1e-12;
+}
+
 // Which pixels of every owned 8x8 quadrant need tracing: on the image, and - when the camera ray's closest hit is
-// cached - not a miss (pathtracer.cpp:550: such a pixel is black for every sample).  One wave per quadrant.
+// cached - not a miss (pathtracer.cpp:550: such a pixel is black for every sample); uncached cameras: not a pixel whose
+// lens rays all miss the scene's bounds (above).  One wave per quadrant.
 __global__ __launch_bounds__(PTK_BLOCK) void live_mask_kernel(const RenderParams P, unsigned long long* mask, int num_subtiles)
 {
     const int subtile = blockIdx.x * (PTK_BLOCK / 64) + (threadIdx.x >> 6);
@@ -1952,6 +2031,7 @@ __global__ __launch_bounds__(PTK_BLOCK) void live_mask_kernel(const RenderParams
         const int px = tx * PTK_TILE + (quad & 1) * 8 + (lane & 7), py = ty * PTK_TILE + (quad >> 1) * 8 + (lane >> 3);
         live = px < P.width && py < P.height;
         if (live && P.primary_hit) live = __float_as_int(P.primary_hit[(size_t)py * P.width + px].x) != PTK_NOHIT;
+        else if (live && P.lens_cull) live = lens_rays_may_reach_scene(P, P.primary[(size_t)py * P.width + px]);
     }
     const unsigned long long m = __ballot(live);
     if (lane == 0) mask[subtile] = m;

@@ -125,6 +125,51 @@ def test_exact_pinhole_primary_cache(tmp_path, oracle_mod, cfg, kw, spp):
     pt.close()
 
 
+@pytest.mark.parametrize("cfg,kw,spp,aperture", [("C3", dict(width=160, height=90), 6, None), ("C3", dict(width=128, height=72), 4, 0.08),
+                                                  ("C1", dict(width=120, height=48), 8, 0.02), ("C4", dict(width=96, height=54, grid=20), 5, 0.15)])
+def test_lens_cull_is_exact(tmp_path, oracle_mod, cfg, kw, spp, aperture):
+    """Thin-lens cameras (pathtracer.cpp:785-791): a pixel NONE of whose lens rays can reach the scene's bounding box is black for
+    every sample, and live_mask_kernel leaves it out of the frame's work (round 4).  The cull is conservative,
+    so the image must equal the oracle's - which shoots every ray - and the cull-disabled kernel's bit for bit, wide apertures
+    (strongly defocused bundles) and camera moves included; and it must actually cull on the 16:9 framings."""
+    from pbrpathtracer_amd import scenes as S
+    from pbrpathtracer_amd.pathtracer import PathTracer, camera_from_scene
+    pts, scene, _ = S.build_config(cfg, str(tmp_path), **kw)
+    pt = PathTracer(0)
+    pt.LoadSceneFile(pts)
+    cam = camera_from_scene(scene)
+    if aperture is not None:
+        pt.SetCameraAperture(aperture); cam["aperture"] = aperture
+    assert cam["aperture"] != 0.0
+    pt.SetSeed(33)
+    W, H = pt.GetResolution(); D = pt.GetTraceDepth()
+    o = oracle_mod.Oracle(pt.StagedScene())
+    for move in (None, ((0.9, 0.3, -3.2), (-0.25, -0.1, 1.0)), ((0.0, 0.0, -9.0), (0.45, 0.0, 1.0))):
+        if move is not None:
+            pt.SetCamera(move[0], move[1], (0, 1, 0)); pt.ResetImage()
+            cam["pos"] = np.array(move[0], np.float32)
+            d = np.array(move[1], np.float32); cam["dir"] = d / np.float32(np.sqrt((d * d).sum(dtype=np.float32)))
+            cam["up"] = np.array([0, 1, 0], np.float32)
+        ctx = pt.context(); ctx.set_option("lens_cull", 1)
+        pt.RenderFrames(spp)
+        assert pt.LastError() == ""
+        culled = pt.ReadAccumulation()
+        st = ctx.collect_stats(0, spp, 33)
+        ctx.set_option("lens_cull", 0)
+        pt.ResetImage(); pt.RenderFrames(spp)
+        plain = pt.ReadAccumulation()
+        st0 = ctx.collect_stats(0, spp, 33)
+        assert st0["paths_started"] == st0["samples"]                      # every pixel traced without the cull
+        assert np.array_equal(culled, plain), move
+        ocam = oracle_mod.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+        ref, _ = o.render(ocam, W, H, D, 0, spp, 33)
+        assert np.array_equal(culled, ref), move
+        if move is None and cfg in ("C3", "C1"):
+            assert st["paths_started"] < 0.7 * st["samples"], (st["paths_started"], st["samples"])     # the box fills a fraction of a wide frame
+        pt.ResetImage()
+    pt.close()
+
+
 def test_exit_from_another_thread(tmp_path):
     """Exit() / GetSamples() are called from the UI thread while the render thread is inside RenderFrame
     (main.cpp:1153, :2277-2324): must be safe.  Exit() cuts the render in flight - whole passes are skipped, an aborted

@@ -351,6 +351,22 @@ def test_psd_and_pic_textures_decode_like_stb_image(tmp_path):
     assert (z["rgba_psd_rgba8_raw_matte"][..., :3] != z["rgba_psd_rgb8_raw"][..., :3]).any()        # the matte removal did something
 
 
+def test_oversized_pic_header_is_refused_not_allocated(tmp_path):
+    """ADVICE r03: a 124-byte Softimage PIC whose header claims 65535 x 65535 asked decode_pic for 17 GB (std::bad_alloc through the
+    C ABI).  stb_image refuses such a file (stbi__mad3sizes_valid, stb_image.h:6440): no texture, no allocation, no exception - checked in
+    a child process whose address space is capped at 4 GB, so that an attempted allocation would end it."""
+    import subprocess
+    import sys
+    pic = bytearray(b"\x53\x80\xf6\x34") + bytearray(84) + bytearray(b"PICT") + bytes([0xff, 0xff, 0xff, 0xff]) + bytearray(8)
+    pic += bytes([0, 8, 0, 0xe0]) + bytearray(16)                  # one uncompressed RGB packet, then too little data
+    path = str(tmp_path / "huge.pic")
+    open(path, "wb").write(bytes(pic))
+    code = ("import resource, sys; resource.setrlimit(resource.RLIMIT_AS, (4 << 30, 4 << 30)); sys.path.insert(0, %r); "
+            "from pbrpathtracer_amd import pathtracer as P; r = P.image_load(%r); print('refused' if r is None else r.shape)") % (ROOT, path)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "refused", (out.returncode, out.stdout, out.stderr[-400:])
+
+
 def _write_png(path, a):
     """Minimal PNG writer (8-bit grey / RGB / RGBA, filter 0) so the test needs no imaging library."""
     import struct
