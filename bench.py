@@ -84,12 +84,42 @@ def parse_args(argv=None):
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check beside the number")
     ap.add_argument("--no-contracted", action="store_true", help="skip the contracted-build measurement")
     ap.add_argument("--no-interactive", action="store_true", help="skip the RenderFrame()-per-iteration measurement")
+    ap.add_argument("--rank-timeout", type=float, default=120.0,
+                    help="N > 1: bound in seconds of every wait on another rank (rendezvous, RCCL communicator, exchange, barriers)")
+    ap.add_argument("--wall-limit", type=float, default=540.0, help="N > 1, self-launched: the parent ends the ranks after this many seconds")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="N > 1: rendezvous + barrier only, no GPU work - exercises the launcher's failure handling (tests)")
     return ap.parse_args(argv)
 
 
+T_START = time.time()
+
+
+def progress(msg: str) -> None:
+    """One stderr line per rank per phase: what a hung or failed N > 1 run was doing last."""
+    print(f"bench.py[rank {os.environ.get('RANK', '0')} +{time.time() - T_START:6.1f}s]: {msg}", file=sys.stderr, flush=True)
+
+
+def fault(phase: str) -> None:
+    """Test hook (PTK_BENCH_FAULT=absent:RANK:PHASE | crash:RANK:PHASE): this rank stops taking part at `phase`."""
+    spec = os.environ.get("PTK_BENCH_FAULT", "")
+    if not spec:
+        return
+    kind, rank, at = (spec.split(":") + ["", ""])[:3]
+    if at == phase and rank == os.environ.get("RANK", "0"):
+        progress(f"FAULT INJECTED: {kind} at {phase}")
+        if kind == "crash":
+            os._exit(7)
+        time.sleep(1e6)
+
+
 def self_launch(args) -> int:
-    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process (never exec: this process may
-    be watched by a profiler that has initialised the GPU), relay rank 0's JSON line, return the child's exit code."""
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process group (never exec: this process may
+    be watched by a profiler that has initialised the GPU), relay rank 0's JSON line, return the child's exit code.  The
+    ranks' stderr - one progress line per rank per phase - passes straight through; a child that is not done after
+    --wall-limit seconds is ended (its own process group, nothing else) and the run exits 124; any rank's failure ends the
+    others (torch.distributed.run) and is named here."""
+    import signal
     import socket
     import subprocess
     s = socket.socket()
@@ -99,21 +129,45 @@ def self_launch(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    # what the run should take: start-up (the first `import torch` of a fresh box pages the image in: up to 2 min), the headline
+    # steps, the contracted build's steps, per-launch timing, counters, the oracle's parity tiles, and - at 8 ranks - C5
+    est = 45.0 + 2.0 * (args.steps + args.warmup) * 0.008 / max(1, args.gpus) + 25.0 + (40.0 if args.gpus == 8 or args.with_c5 else 0.0)
+    print(f"bench.py: starting {args.gpus} ranks on 127.0.0.1:{port}; expected wall time about {est:.0f} s (up to {est + 120:.0f} s on a "
+          f"freshly booted box), every wait on another rank bounded by {args.rank_timeout:.0f} s, hard limit {args.wall_limit:.0f} s", file=sys.stderr, flush=True)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=args.wall_limit)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the ranks were not done after {args.wall_limit:.0f} s - ending them (the last progress line of each rank above "
+              f"says where it stood)", file=sys.stderr, flush=True)
+        try:
+            os.killpg(p.pid, signal.SIGTERM)            # the child's own session: torch.distributed.run and its ranks, nothing else
+            out, _ = p.communicate(timeout=15)
+        except (subprocess.TimeoutExpired, ProcessLookupError):
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            out, _ = p.communicate()
+        return 124
     line = None
-    for ln in p.stdout.splitlines():
+    for ln in (out or "").splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
         elif ln.strip():
             print(ln, file=sys.stderr)
+    if p.returncode != 0:
+        print(f"bench.py: torch.distributed.run exited with code {p.returncode}: a rank failed or timed out (its own message and "
+              f"torchrun's failure table - rank, local_rank, exitcode - are above)", file=sys.stderr, flush=True)
+        return p.returncode if p.returncode > 0 else 1
     if line is not None:
         print(line)
-    elif p.returncode == 0:
+    else:
         print("bench.py: the ranks exited 0 but rank 0 printed no result line", file=sys.stderr)
         return 4
-    return p.returncode
+    return 0
 
 
 def sha256_of(path: str):
@@ -314,11 +368,14 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
         print("bench.py: " + pt.LastError(), file=sys.stderr)
         sys.exit(3)
     ctx = pt.context()
+    ctx.set_option("comm_timeout_s", args.rank_timeout)           # every wait of the exchange step is bounded
     for kv in args.opts.split(","):
         if "=" in kv:
             k, v = kv.split("=")
             ctx.set_option(k, float(v))
     ctx.reset()
+    if world > 1:
+        progress(f"{name}: scene loaded ({t_load:.2f} s), BVH built, first frame rendered")
 
     # ---- exchange step ------------------------------------------------------------------------------
     exchange, host_accum = None, None
@@ -340,6 +397,8 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
         info = ctx.comm_info()                  # what the library's own communicator reports - not torch's WORLD_SIZE
         comm["rccl_ranks"] = info["world"]
         comm["devices"] = [info["comm_device"]]
+        if world > 1:
+            progress(f"{name}: RCCL communicator up ({info['world']} ranks, this one on device {info['comm_device']})")
     if world > 1:
         # the distinct HIP ordinals the ranks render on (one node: N ranks must mean N devices)
         box = [None] * world
@@ -354,6 +413,7 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
     def step(first, i, last):
         ctx.render(first, spp, args.seed)
         if exchange is not None and ((i + 1) % every == 0 or last):
+            fault("exchange")
             if rehearsal:
                 host_accum.copy_(torch.from_numpy(ctx.read_accum().reshape(-1)))    # (synchronises; rehearsal only)
             exchange.start()
@@ -370,25 +430,35 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
 
     first = [0]
 
-    def timed(n_warm, n_steps):
-        """n_warm untimed steps, then exactly n_steps between two fences; max over ranks; returns seconds"""
+    launch_log = {}
+
+    def timed(n_warm, n_steps, log_key=None):
+        """n_warm untimed steps, then exactly n_steps between two fences; max over ranks; returns seconds.  With log_key the
+        duration of EVERY trace launch inside the timed region is kept (HIP events on the launch's own stream: ptk_kernel_log)."""
         for i in range(n_warm):
             step(first[0], i, i == n_warm - 1); first[0] += spp
         fence()
+        if log_key:
+            ctx.kernel_log(min(n_steps * 16 + 16, 1 << 16))
         exchanges[0] = 0
         t0 = time.perf_counter()
         for i in range(n_steps):
             step(first[0], i, i == n_steps - 1); first[0] += spp
         fence()
         el = time.perf_counter() - t0
+        if log_key:
+            launch_log[log_key] = ctx.kernel_log_read()
+            ctx.kernel_log(0)
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el
 
-    elapsed = timed(warmup, steps)
+    elapsed = timed(warmup, steps, log_key="exact")
     timed_exchanges = exchanges[0]
+    if world > 1:
+        progress(f"{name}: {steps} timed steps done, {elapsed / steps * 1e3:.3f} ms per step, {timed_exchanges} exchanges")
     checksum = None
     if world > 1 and exchange is not None:
         # property check of the exchange: the gathered image holds exactly what the ranks hold together
@@ -422,9 +492,9 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
     # finishing, which is what `value` measures; a per-launch duration only means something in isolation
     ev_ms, acc_ms = [], []
     ctx.set_option("overlap", 0)
-    for _ in range(max(1, min(steps, 3))):
+    for _ in range(max(1, min(steps, 5))):
         ctx.render(first[0], spp, args.seed); first[0] += spp
-        t_ms, a_ms = ctx.last_kernel_ms()
+        t_ms, a_ms = ctx.last_kernel_ms()                       # (waits for the render: launches are isolated from one another)
         ev_ms.append(t_ms); acc_ms.append(a_ms)
         passes = max(1, ctx.last_render_ms()[1] // 3)          # trace_kernel launches per step (the sample buffer bounds a launch)
     ctx.set_option("overlap", 1)
@@ -466,7 +536,12 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
     step_s = ms_per_step * 1e-3
     valu_tflops = d4_flops * step_samples / step_s / 1e12 / world      # per GPU
     d4_gbps = d4_bytes * step_samples / step_s / 1e9 / world
-    kernel_ms = float(np.mean(ev_ms))
+    # per step, isolated: the MEDIAN of the launches above (every one of them is in the line: the first after a pause runs at
+    # another clock than the rest, which a mean hides - VERDICT r03 item 3)
+    kernel_ms = float(np.median(ev_ms))
+    # per launch, INSIDE the timed region (overlapped tails included): what roofline.frac_from_kernel_ms is computed from
+    in_loop = np.array(launch_log.get("exact") or [0.0], np.float64)
+    loop_launch_ms = float(np.median(in_loop))
     traffic, traffic_src, cache, traffic_note = None, None, None, None
     traffic_file = os.path.join(ROOT, "profiles", f"traffic_{name}.json")
     if os.path.exists(traffic_file):
@@ -496,7 +571,15 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
     roofline.update({
         "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
         "kernel": "trace_kernel<FLAT>" if flat else "trace_kernel<BVH>", "kernel_ms_isolated": round(kernel_ms, 4),
+        "kernel_ms_isolated_each": [round(float(x), 4) for x in ev_ms],
+        "kernel_ms_isolated_note": "trace launches of one step summed, per isolated step (overlap off, each waited for); the headline figure is their median",
         "trace_launches_per_step": passes,
+        # every trace launch of the TIMED region, event-timed on its own stream while the launches overlap their tails
+        "kernel_ms_in_loop": {"launches": int(in_loop.size), "min": round(float(in_loop.min()), 4), "median": round(loop_launch_ms, 4),
+                              "mean": round(float(in_loop.mean()), 4), "max": round(float(in_loop.max()), 4)},
+        "frac_from_kernel_ms": round(d4_flops * step_samples / max(1e-9, loop_launch_ms * passes * 1e-3) / 1e12 / world / VALU_PEAK_TFLOPS, 4),
+        "frac_from_kernel_ms_note": "SURVEY 8(d4) flops of one step / (median in-loop launch duration x launches per step) / 157.3 TFLOP/s: recompute it from "
+                                    "valu.flops_per_sample x width x height x spp_per_step and profiles/r04/rocprofv3_kernel_stats_<config>.csv",
         "accumulate_kernel_ms": round(float(np.mean(acc_ms)), 4),
         "computed_from": "ms_per_step (timed region; consecutive launches overlap their tails - profiles/r03/overlap_trace_C2.json - so a step is shorter than an isolated launch)",
         "valu": {"flops_per_sample": round(d4_flops, 1), "achieved_TFLOPs": round(valu_tflops, 2), "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4),
@@ -542,7 +625,9 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
         "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "traced_samples_per_s": round(value * live_fraction, 2),
+        # what compares across rounds and configs: the samples that are actually traced (value counts every pixel of the frame;
+        # live_fraction = pixels whose camera rays can hit anything - the exact culls skip the rest)
+        "traced_samples_per_s": round(value * live_fraction, 2), "live_fraction": round(live_fraction, 4),
         "config": {"workload": WORKLOADS[name], "name": name, "width": W, "height": H, "max_depth": D, "spp_per_step": spp,
                    "triangles": ntri, "bvh_nodes": nodes, "bvh_depth": depth,
                    "parallelism": f"tile-split x{world}" if world > 1 else "single GPU",
@@ -589,10 +674,11 @@ def short(o):
     """numbers and short keys of a measure() result, for other_configs (the driver keeps only the tail of the line)"""
     r = o["roofline"]
     d = {"value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"], "n_gpus": o["n_gpus"],
-         "traced_samples_per_s": o["traced_samples_per_s"],
+         "traced_samples_per_s": o["traced_samples_per_s"], "live_fraction": o["live_fraction"],
          "workload": o["config"]["workload"], "triangles": o["config"]["triangles"], "bvh_nodes": o["config"]["bvh_nodes"],
          "roofline": {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
-                      "traffic": r["traffic"], "kernel_ms_isolated": r["kernel_ms_isolated"], "launches_per_step": r["trace_launches_per_step"],
+                      "traffic": r["traffic"], "kernel_ms_isolated": r["kernel_ms_isolated"], "kernel_ms_isolated_each": r["kernel_ms_isolated_each"],
+                      "kernel_ms_in_loop": r["kernel_ms_in_loop"], "frac_from_kernel_ms": r["frac_from_kernel_ms"], "launches_per_step": r["trace_launches_per_step"],
                       "valu_frac": r["valu"]["frac"], "lane_utilisation_offline": r["valu"].get("lane_utilisation_offline"),
                       "l2_hit_rate": (r["hbm"]["cache"] or {}).get("l2_hit_rate") if r["hbm"].get("cache") else None,
                       "counter_GBps": r["hbm"]["counter_GBps"], "per_sample": r["per_sample"], "simd_lane_utilisation": r["simd_lane_utilisation"]},
@@ -619,8 +705,25 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
 
+    import datetime
     import torch
     import torch.distributed as dist
+    pg_timeout = datetime.timedelta(seconds=args.rank_timeout)
+
+    if args.rehearse_launch:
+        # launcher rehearsal (CPU): rendezvous, one barrier, a stub line - no GPU, no rendering
+        progress("up")
+        fault("rendezvous")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
+        progress("process group up")
+        fault("barrier")
+        dist.barrier()
+        progress("barrier passed")
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "launch rehearsal", "value": 0.0, "n_gpus": world}))
+        return
 
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the render path has no CPU fallback", file=sys.stderr)
@@ -631,12 +734,15 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        progress(f"up on HIP device {local_rank} of {torch.cuda.device_count()}")
+        fault("rendezvous")
         if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
         else:
             # torch.distributed is the rendezvous (RCCL id broadcast, barrier, max-over-ranks time); the data-path
             # collective runs on the library's own communicator and stream
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
+        progress("process group up")
 
     out, scene = measure(args.config, args, rank, world, local_rank, args.steps, args.warmup, headline=True)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -649,9 +755,9 @@ def main():
     others = {}
     if world == 1 and not args.no_other_configs and args.config == "C2" and not args.opts:
         # the BVH-walk configs at their full BASELINE size, through the identical code path (numbers + short keys only)
-        for name, k in (("C3", 3), ("C4", 3), ("C5", 2)):
+        for name, k in (("C3", 4), ("C4", 4), ("C5", 3)):
             try:
-                o, _ = measure(name, args, 0, 1, local_rank, k, 1, headline=False)
+                o, _ = measure(name, args, 0, 1, local_rank, k, 2, headline=False)
                 others[name] = short(o)
             except Exception as e:
                 others[name] = {"value": None, "error": f"{type(e).__name__}: {e}"}

@@ -160,9 +160,11 @@ public:
     // The reference seeds one std::mt19937 from std::random_device (pathtracer.cpp:11); here the RNG
     // is counter-based and keyed on (seed, pixel, sample index), default seed 0.
     void SetSeed(uint64_t seed);
-    // SetOutImage for a display path that stays on the GPU: the 8-bit image (the layout of texData) is written into this
-    // OpenGL buffer object - the viewer's GL_PIXEL_UNPACK_BUFFER - instead of a host buffer (ptk_bind_gl_buffer, include/ptk.h;
-    // call with the viewer's OpenGL context current, as everything in main.cpp is).  0 or SetOutImage(ptr) switches back.
+    // EXPERIMENTAL (never executed: headless build boxes).  SetOutImage for a display path that stays on the GPU: the 8-bit image
+    // (the layout of texData) is written into this OpenGL buffer object - the viewer's GL_PIXEL_UNPACK_BUFFER - instead of a host
+    // buffer.  Call it on the thread whose OpenGL context is current (the viewer's GUI thread): the buffer is registered HERE
+    // (ptk_bind_gl_buffer, include/ptk.h), not inside RenderFrame(), which the viewer runs on a thread without a context; the call
+    // waits for a RenderFrame() in flight.  Read the buffer only between two RenderFrame() calls.  0 lets it go (same thread).
     void SetOutGLBuffer(unsigned int gl_buffer);
     // ... or into W*H*3 bytes of this GPU's memory (ptk_bind_out_device); NULL or SetOutImage(ptr) switches back.
     void SetOutDeviceImage(void* device_rgb8);

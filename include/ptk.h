@@ -139,26 +139,33 @@ int ptk_render(ptk_ctx* ctx, uint32_t first_sample, uint32_t spp_count, uint64_t
  * W*H*3 bytes, RGB, rows bottom-up, tightly packed; waits for the stream */
 int ptk_resolve_rgb8(ptk_ctx* ctx, uint8_t* host_out);
 /* SetOutImage (pathtracer.cpp:297-300) for the interactive loop - one RenderFrame(), one glTexSubImage2D(texData)
- * (main.cpp:3587, :3026-3029): binds the caller's W*H*3 hand-off buffer so that the accumulate kernel's 8-bit resolve
- * (pathtracer.cpp:802-812) is written STRAIGHT into it over PCIe, and ptk_resolve_rgb8 into the bound buffer only waits
- * for the stream - no copy command, no second launch.  A buffer from ptk_host_alloc is used as it is; any other buffer
- * (`new GLubyte[w*h*3]`, main.cpp:3435) is page-locked in place for as long as it is bound.  If neither works the call
- * still succeeds and ptk_resolve_rgb8 copies as before.  NULL unbinds; ptk_set_frame with another resolution unbinds too
- * (the caller reallocates texData then, main.cpp:3425-3446).  The buffer stays caller-owned and must stay ALLOCATED while it is
- * bound: unbind (NULL, or bind its successor) BEFORE freeing it - memory freed while still page-locked through the runtime
- * poisons whatever the allocator places there next (PathTracer::SetOutImage does this for the class's users).  While bound,
- * renders run on the context's stream alone (each frame is waited for anyway). */
+ * (main.cpp:3587, :3026-3029): binds a W*H*3 hand-off buffer THE GPU CAN WRITE - memory from ptk_host_alloc, or memory the caller
+ * page-locked and mapped itself - so that the accumulate kernel's 8-bit resolve (pathtracer.cpp:802-812) is written STRAIGHT into
+ * it over PCIe, and ptk_resolve_rgb8 into the bound buffer only waits for the stream: no copy command, no second launch.
+ * Ordinary pageable memory (`new GLubyte[w*h*3]`, main.cpp:3435) is NOT bound and never registered with the runtime: the call
+ * succeeds, and ptk_resolve_rgb8 copies the frame into it as before.  (Round 3 page-locked such a buffer in place; the reference's
+ * viewer deletes texData BEFORE handing over its successor - InitializeFrame, main.cpp:3433-3445 - and at exit without telling
+ * the tracer - OnExit, :3622 - and memory freed while registered poisons what the allocator puts there next.)
+ * ptk_set_option("register_out_image", 1) opts back in to page-locking in place, for callers that promise to unbind - NULL, or
+ * the successor - BEFORE they free a bound buffer.  NULL unbinds; ptk_set_frame with another resolution unbinds too (the caller
+ * reallocates texData then, main.cpp:3425-3446).  A bound buffer stays caller-owned and must stay allocated while a render is
+ * in flight.  While a buffer is bound, renders run on the context's stream alone (each frame is waited for anyway).
+ * Threading: like every call that takes the context, from one thread at a time (the thread that renders); the C++ class's
+ * SetOutImage is a pointer store for that reason and binds on the render thread. */
 int ptk_bind_out_image(ptk_ctx* ctx, uint8_t* host_out);
 /* The same hand-off without the PCIe hop, for a display path that lives on the GPU (N3: the viewer's frameTex ← texData upload,
  * main.cpp:3026-3029, :3425-3446).  The accumulate kernel writes the 8-bit image - W*H*3 bytes, RGB, rows bottom-up, the layout
  * of texData - into the bound DEVICE memory; ptk_synchronize waits for it.  One binding at a time: binding a host buffer, a
  * device buffer or an OpenGL buffer replaces whatever was bound; NULL / 0 unbinds; ptk_set_frame with another resolution unbinds.
  *   ptk_bind_out_device: any allocation of this context's GPU (hipMalloc, a torch tensor, imported external memory).
- *   ptk_bind_gl_buffer:  an OpenGL buffer object of >= W*H*3 bytes (the viewer's pixel-unpack buffer), registered with
- *     hipGraphicsGLRegisterBuffer and mapped only for the length of each ptk_render (HIP owns it between map and unmap; the
- *     unmap is ordered behind the kernel that writes it, so a glTexSubImage2D from the buffer issued after ptk_render has
- *     returned reads the finished frame).  Must be called on the thread whose OpenGL context is current; without one the
- *     call fails with PTK_ERR_BAD_ARG (the library does not link OpenGL and never creates a context).
+ *   ptk_bind_gl_buffer:  EXPERIMENTAL - an OpenGL buffer object of >= W*H*3 bytes (the viewer's pixel-unpack buffer), registered
+ *     with hipGraphicsGLRegisterBuffer HERE, on the calling thread, which must be the one whose OpenGL context is current (the
+ *     viewer's GUI thread; without a current context the call fails with PTK_ERR_BAD_ARG - the library does not link OpenGL and
+ *     never creates a context); 0 lets the registration go, on the same thread.  ptk_render - on the render thread, which needs no
+ *     context - maps the buffer on its stream before the first pass and unmaps it behind the kernel that writes it: HIP owns the
+ *     buffer for the length of a ptk_render, so the GUI thread may source a glTexSubImage2D from it only BETWEEN renders (the same
+ *     sequencing texData needs).  A new resolution keeps the registration; the buffer's size is checked at every map.  No frame
+ *     needs to be set when this is called.
  *     NOT exercised on hardware: the build boxes are headless (no display server, no EGL); only the error paths are tested. */
 int ptk_bind_out_device(ptk_ctx* ctx, void* device_rgb8);
 int ptk_bind_gl_buffer(ptk_ctx* ctx, unsigned int gl_buffer);
@@ -255,6 +262,13 @@ int ptk_set_option(ptk_ctx* ctx, const char* name, double value);
  * predecessor's tail still holds: set "overlap" 0 for isolated per-launch durations (bench.py does) */
 int ptk_last_render_ms(ptk_ctx* ctx, float* ms, int* launches);
 int ptk_last_kernel_ms(ptk_ctx* ctx, float* trace_ms, float* accumulate_ms);
+/* ... and of EVERY trace-kernel launch of a stretch of renders, overlapped or not, each timed with a pair of HIP events on the
+ * stream the kernel is launched on (the events sit behind the launch's stream waits: a duration is the kernel's own, from the
+ * moment it may start).  ptk_kernel_log(ctx, capacity) starts a log of up to `capacity` launches (0 stops and frees it);
+ * ptk_kernel_log_read waits for the streams and returns the durations in launch order (bench.py: the per-launch times INSIDE
+ * its timed region, beside ms_per_step). */
+int ptk_kernel_log(ptk_ctx* ctx, int capacity);
+int ptk_kernel_log_read(ptk_ctx* ctx, float* trace_ms, int max_entries, int* num_entries);
 int ptk_collect_stats(ptk_ctx* ctx, uint32_t first_sample, uint32_t spp_count, uint64_t seed, ptk_stats* out);
 int ptk_bvh_info(ptk_ctx* ctx, int32_t* num_nodes, int32_t* depth /* wide nodes on the longest chain */, int32_t* num_leaf_tris);
 /* child boxes per node record (4), bytes per record (64), most stack entries a traversal of this tree can need */

@@ -15,7 +15,9 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh_build.h"
@@ -140,7 +142,16 @@ struct ptk_ctx {
     float* d_gathered = nullptr; size_t gathered_floats = 0;  // root: the combined image (W*H*3, rows bottom-up)
     int gathered_w = 0, gathered_h = 0;          // the frame the last ptk_gather_accum combined (ptk_read_gathered refuses any other)
     bool gather_pending = false;
+    // every wait of the exchange step is bounded (ptk_set_option "comm_timeout_s"): a rank that never arrives must end the run with
+    // an error that names it, not hang the node (the first real 8-GPU run is the driver's, not ours)
+    double opt_comm_timeout_s = 120.0;
+    unsigned long long gather_step = 0;          // exchanges queued so far (named in the timeout message)
+    size_t gather_bytes = 0;                     // bytes the last exchange moves on this rank (root: what it receives)
+    int gather_root = 0;
 
+    // log of every trace launch's duration (ptk_kernel_log): event pairs on the launch's own stream
+    std::vector<hipEvent_t> klog_ev;             // 2 x capacity
+    int klog_n = 0;
     static constexpr int kMaxTimedPasses = 64;
     hipEvent_t ev[kMaxTimedPasses][3] = {};      // per pass: before trace, after trace, after accumulate
     int last_passes = 0;
@@ -517,12 +528,15 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
         p.num_items = (int)items;
         const int pi = c->last_passes < ptk_ctx::kMaxTimedPasses ? c->last_passes : -1;
         if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][0], tstream));
+        const int kl = (!stats && (size_t)(2 * c->klog_n + 1) < c->klog_ev.size()) ? c->klog_n : -1;
+        if (kl >= 0) HIPCHK(c, hipEventRecord(c->klog_ev[2 * kl], tstream));
         p.queues = overlap ? c->d_queues2[b] : c->d_queues;
         if (c->opt_contract == 1 && !stats) fma::launch_trace(p, tiles * 4, c->resident_waves, tstream, false);
         else if (c->opt_contract == 2 && !stats) fast::launch_trace(p, tiles * 4, c->resident_waves, tstream, false);
         else launch_trace(p, tiles * 4, c->resident_waves, tstream, stats);
         HIPCHK(c, hipGetLastError());
         if (timed && pi >= 0) HIPCHK(c, hipEventRecord(c->ev[pi][1], tstream));
+        if (kl >= 0) { HIPCHK(c, hipEventRecord(c->klog_ev[2 * kl + 1], tstream)); c->klog_n = kl + 1; }
         if (overlap)
         {
             HIPCHK(c, hipEventRecord(c->ev_trace_done[b], tstream));
@@ -628,6 +642,7 @@ void ptk_destroy(ptk_ctx* c)
     for (int i = 0; i < ptk_ctx::kMaxTimedPasses; i++)
         for (int k = 0; k < 3; k++)
             if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
+    for (hipEvent_t e : c->klog_ev) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1304,10 +1319,39 @@ int ptk_comm_init(ptk_ctx* c, const void* id_in, int rank, int world)
     if (!c || !id_in || world < 1 || world > PTK_MAX_RANKS || rank < 0 || rank >= world) return PTK_ERR_BAD_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    // ncclCommInitRank blocks until EVERY rank of the group has called it: a rank that died on the way (or was never started)
+    // would hang the others for good.  It runs on a helper thread and is waited for with a bound; on a timeout the caller gets an
+    // error that names the rank and is expected to end the process (the helper thread is abandoned with its own state).
+    struct InitJob { ncclComm_t comm = nullptr; ncclResult_t r = ncclSuccess; std::atomic<int> done{ 0 }; };
+    auto job = std::make_shared<InitJob>();
     ncclUniqueId id;
     std::memcpy(&id, id_in, sizeof(id));
-    ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
-    if (r != ncclSuccess) { c->comm = nullptr; return fail(c, PTK_ERR_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+    const int device = c->device;
+    std::thread([job, id, rank, world, device] {
+        (void)hipSetDevice(device);
+        job->r = ncclCommInitRank(&job->comm, world, id, rank);
+        job->done.store(1);
+    }).detach();
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!job->done.load())
+    {
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > c->opt_comm_timeout_s)
+        {
+            char msg[256];
+            std::snprintf(msg, sizeof(msg), "ncclCommInitRank: rank %d of %d (HIP device %d) waited %.0f s for the other ranks to join the communicator - "
+                          "is every rank running, on a device of its own?", rank, world, device, waited);
+            return fail(c, PTK_ERR_RCCL, msg);
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+    if (job->r != ncclSuccess || !job->comm)
+    {
+        char msg[256];
+        std::snprintf(msg, sizeof(msg), "ncclCommInitRank: rank %d of %d (HIP device %d): %s", rank, world, device, ncclGetErrorString(job->r));
+        return fail(c, PTK_ERR_RCCL, msg);
+    }
+    c->comm = job->comm;
     c->comm_rank = rank; c->comm_world = world;
     c->rank = rank; c->world = world;            // the frame is split over the group (ptk_set_tile)
     return PTK_OK;
@@ -1407,15 +1451,46 @@ int ptk_gather_accum(ptk_ctx* c, void* rccl_comm, int root)
     }
     HIPCHK(c, hipEventRecord(c->ev_gathered, c->xstream));
     c->gather_pending = true;
+    c->gather_step++; c->gather_root = root;
+    c->gather_bytes = (rank == root ? total - mine : mine) * sizeof(float);
     return PTK_OK;
 }
 
+// Bounded: polls the exchange's last event; when it has not fired within comm_timeout_s (a rank never entered its
+// ptk_gather_accum, or died in it) the communicator is aborted - which releases the transfer kernel stuck on the exchange
+// stream - and the caller gets PTK_ERR_RCCL with rank, step and the bytes that were expected.  An asynchronous RCCL error
+// (a peer's process gone) ends the wait at once.
 int ptk_gather_wait(ptk_ctx* c)
 {
     if (!c) return PTK_ERR_BAD_ARG;
     if (!c->gather_pending) return PTK_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipEventSynchronize(c->ev_gathered));
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;)
+    {
+        const hipError_t q = hipEventQuery(c->ev_gathered);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { c->gather_pending = false; return fail(c, PTK_ERR_HIP, std::string("hipEventQuery (exchange): ") + hipGetErrorString(q)); }
+        (void)hipGetLastError();
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ncclResult_t async = ncclSuccess;
+        const bool poll_comm = c->comm && (++spins & 1023u) == 0;
+        if (poll_comm && ncclCommGetAsyncError(c->comm, &async) != ncclSuccess) async = ncclSystemError;
+        if (waited > c->opt_comm_timeout_s || (async != ncclSuccess && async != ncclInProgress))
+        {
+            char msg[384];
+            std::snprintf(msg, sizeof(msg), "exchange step %llu on rank %d of %d (root %d) %s after %.1f s: %s %zu bytes%s",
+                          c->gather_step, c->rank, c->world, c->gather_root,
+                          async != ncclSuccess && async != ncclInProgress ? "failed" : "timed out", waited,
+                          c->rank == c->gather_root ? "still expecting" : "still sending", c->gather_bytes,
+                          async != ncclSuccess && async != ncclInProgress ? (std::string(" - RCCL: ") + ncclGetErrorString(async)).c_str() : " - a rank never joined this step");
+            if (c->comm) { (void)ncclCommAbort(c->comm); c->comm = nullptr; }
+            c->gather_pending = false;
+            return fail(c, PTK_ERR_RCCL, msg);
+        }
+        if (waited > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
     c->gather_pending = false;
     return PTK_OK;
 }
@@ -1496,6 +1571,35 @@ int ptk_last_render_ms(ptk_ctx* c, float* ms, int* launches)
     return rc;
 }
 
+int ptk_kernel_log(ptk_ctx* c, int capacity)
+{
+    if (!c || capacity < 0 || capacity > (1 << 20)) return PTK_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    for (hipEvent_t e : c->klog_ev) (void)hipEventDestroy(e);
+    c->klog_ev.clear(); c->klog_n = 0;
+    for (int i = 0; i < 2 * capacity; i++)
+    {
+        hipEvent_t e = nullptr;
+        HIPCHK(c, hipEventCreate(&e));
+        c->klog_ev.push_back(e);
+    }
+    return PTK_OK;
+}
+
+int ptk_kernel_log_read(ptk_ctx* c, float* trace_ms, int max_entries, int* num_entries)
+{
+    if (!c || !num_entries || (max_entries > 0 && !trace_ms)) return PTK_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int k = 0; k < 2; k++) if (c->trace_stream[k]) HIPCHK(c, hipStreamSynchronize(c->trace_stream[k]));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int n = std::min(c->klog_n, max_entries);
+    for (int i = 0; i < n; i++) HIPCHK(c, hipEventElapsedTime(&trace_ms[i], c->klog_ev[2 * i], c->klog_ev[2 * i + 1]));
+    *num_entries = n;
+    c->klog_n = 0;
+    return PTK_OK;
+}
+
 int ptk_last_kernel_ms(ptk_ctx* c, float* trace_ms, float* accumulate_ms)
 {
     if (!c || !trace_ms || !accumulate_ms) return PTK_ERR_BAD_ARG;
@@ -1532,6 +1636,13 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
     if (!std::strcmp(name, "overlap"))
     {
         c->opt_overlap = value != 0.0 ? 1 : 0;
+        return PTK_OK;
+    }
+    if (!std::strcmp(name, "comm_timeout_s"))
+    {
+        // bound of every wait of the exchange step (ptk_comm_init, ptk_gather_wait, ptk_read_gathered)
+        if (!(value >= 0.05 && value <= 86400.0)) return fail(c, PTK_ERR_BAD_ARG, "comm_timeout_s must be in [0.05, 86400]");
+        c->opt_comm_timeout_s = value;
         return PTK_OK;
     }
     if (!std::strcmp(name, "lens_cull"))

@@ -70,7 +70,7 @@ SYMBOLS = [
     "ptk_bvh_info", "ptk_bvh_layout", "ptk_upload_timing", "ptk_download_bvh", "ptk_probe_hits", "ptk_probe_primary_dirs", "ptk_probe_math", "ptk_probe_direct", "ptk_host_alloc", "ptk_host_free",
     "ptk_packed_floats", "ptk_packed_layout", "ptk_comm_unique_id", "ptk_comm_init", "ptk_comm_destroy",
     "ptk_gather_wait", "ptk_read_gathered", "ptk_gathered_device_ptr", "ptk_probe_pack", "ptk_probe_unpack",
-    "ptk_bind_out_image", "ptk_bind_out_device", "ptk_bind_gl_buffer", "ptk_comm_info",
+    "ptk_bind_out_image", "ptk_bind_out_device", "ptk_bind_gl_buffer", "ptk_comm_info", "ptk_kernel_log", "ptk_kernel_log_read",
 ]
 
 
@@ -137,6 +137,8 @@ def _load_locked() -> C.CDLL:
     L.ptk_last_kernel_ms.argtypes = [vp, fp, fp]
     L.ptk_set_option.argtypes = [vp, C.c_char_p, C.c_double]
     L.ptk_collect_stats.argtypes = [vp, u32, u32, u64, C.POINTER(Stats)]
+    L.ptk_kernel_log.argtypes = [vp, i32]
+    L.ptk_kernel_log_read.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]
     L.ptk_bvh_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ptk_bvh_layout.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ptk_download_bvh.argtypes = [vp, vp, vp]
@@ -268,6 +270,18 @@ class Context:
         t = C.c_float(0); a = C.c_float(0)
         self._chk(self.L.ptk_last_kernel_ms(self.h, C.byref(t), C.byref(a)), "ptk_last_kernel_ms")
         return t.value, a.value
+
+    def kernel_log(self, capacity: int):
+        """Start (capacity > 0) or stop (0) the log of every trace launch's duration."""
+        self._chk(self.L.ptk_kernel_log(self.h, int(capacity)), "ptk_kernel_log")
+        self._klog_cap = int(capacity)
+
+    def kernel_log_read(self):
+        """Durations (ms) of the trace launches since the log was started / last read, in launch order."""
+        cap = max(1, getattr(self, "_klog_cap", 0))
+        buf = (C.c_float * cap)(); n = C.c_int(0)
+        self._chk(self.L.ptk_kernel_log_read(self.h, buf, cap, C.byref(n)), "ptk_kernel_log_read")
+        return [float(buf[i]) for i in range(n.value)]
 
     def set_option(self, name: str, value: float):
         self._chk(self.L.ptk_set_option(self.h, name.encode(), float(value)), "ptk_set_option")

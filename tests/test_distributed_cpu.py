@@ -137,3 +137,39 @@ def test_packed_layout_matches_the_tile_map():
             assert (first[..., 1][on] == first[..., 0][on] + 1).all() and (first[..., 2][on] == first[..., 0][on] + 2).all()
         assert (seen == 1).all()
     assert ptk.load().ptk_packed_floats(0, 10, 0, 1) < 0 and ptk.load().ptk_packed_floats(10, 10, 2, 2) < 0
+
+
+@pytest.mark.parametrize("fault,culprit", [("absent:1:rendezvous", None), ("absent:1:barrier", None), ("crash:1:barrier", "exitcode  : 7")])
+def test_bench_launcher_ends_a_run_with_a_missing_or_dead_rank(fault, culprit):
+    """the first real `bench.py --gpus 8` is the driver's, so it must not be able to hang.  The launcher
+    rehearsal (`--rehearse-launch`: rendezvous + barrier over gloo, no GPU work) with one rank that never arrives, stops before a
+    barrier, or dies: every wait on another rank is bounded by --rank-timeout, the parent exits NON-ZERO well inside the bound,
+    prints no result line, and the ranks' progress lines / torchrun's failure table say which rank it was."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PTK_BENCH_FAULT"] = fault
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch", "--rank-timeout", "6", "--wall-limit", "90"],
+                       capture_output=True, text=True, timeout=240, cwd=ROOT, env=env)
+    took = time.time() - t0
+    assert r.returncode != 0 and took < 80, (r.returncode, took, r.stderr[-1500:])
+    assert '"metric"' not in r.stdout
+    assert "FAULT INJECTED" in r.stderr and "bench.py[rank 1" in r.stderr             # the culprit's last progress line
+    assert "a rank failed or timed out" in r.stderr
+    if culprit:
+        assert culprit in r.stderr and "rank      : 1" in r.stderr
+
+
+def test_bench_launcher_wall_limit_ends_ranks_that_never_finish():
+    """... and when no rank's own bound fires in time (here: a bound of ten minutes), the parent's wall limit ends the child's
+    process group - torch.distributed.run and its ranks, nothing else - and the run exits 124."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PTK_BENCH_FAULT"] = "absent:0:rendezvous"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch", "--rank-timeout", "600", "--wall-limit", "12"],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode == 124 and time.time() - t0 < 60, (r.returncode, r.stderr[-1500:])
+    assert "were not done after 12 s" in r.stderr and '"metric"' not in r.stdout

@@ -127,6 +127,45 @@ def test_bench_two_ranks_rehearsal_self_launched():
     assert c5["config"]["exchanges_in_timed_region"] == 1 and c5["parity"]["ok"] is True
 
 
+def test_bench_rank_absent_at_the_exchange_ends_the_run_within_the_bound():
+    """a rank that renders but never enters the exchange step (PTK_BENCH_FAULT: it stops right before its first
+    gather) must end `bench.py --gpus 2` with a non-zero exit inside the bound - rank 0's wait on the gather times out
+    (--rank-timeout), torch.distributed.run ends the other rank, the parent names the failure and prints no result line."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["PTK_BENCH_FAULT"] = "absent:1:exchange"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "C1",
+                        "--backend", "gloo", "--exchange-every", "1", "--no-cpu-baseline", "--rank-timeout", "10", "--wall-limit", "300"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    took = time.time() - t0
+    assert r.returncode != 0 and took < 280, (r.returncode, took, r.stderr[-3000:])
+    assert '"metric"' not in r.stdout
+    assert "FAULT INJECTED: absent at exchange" in r.stderr and "a rank failed or timed out" in r.stderr, r.stderr[-3000:]
+
+
+def test_native_gather_wait_is_bounded():
+    """ptk_gather_wait / ptk_comm_init never wait for ever: with comm_timeout_s set to a fraction of a second a communicator whose
+    second rank never joins is refused with PTK_ERR_RCCL naming rank, world and device (the helper thread that sits in
+    ncclCommInitRank is abandoned; this test runs it in a child process that is ended afterwards)."""
+    code = (
+        "import sys, time; sys.path.insert(0, %r)\n"
+        "from pbrpathtracer_amd import ptk\n"
+        "ctx = ptk.Context(0)\n"
+        "ctx.set_option('comm_timeout_s', 0.5)\n"
+        "uid = ptk.comm_unique_id()\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        "    ctx.comm_init(uid, 0, 2)\n"
+        "    print('JOINED')\n"
+        "except ptk.PtkError as e:\n"
+        "    print('REFUSED in %%.1f s: %%s' %% (time.time() - t0, e))\n"
+        "sys.stdout.flush()\n"
+        "import os; os._exit(0)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert "REFUSED" in r.stdout and "rank 0 of 2" in r.stdout and "waited" in r.stdout, (r.stdout, r.stderr[-2000:])
+
+
 def test_native_gather_between_two_gpus(tmp_path):
     """The N > 1 branch of ptk_gather_accum (grouped ncclSend / ncclRecv on the library's own communicator, exchange
     stream next to persistent trace waves) with two real ranks: two fresh child processes, one GPU each, render their

@@ -306,8 +306,8 @@ def test_page_locked_handoff_buffer(tmp_path):
 
 def test_bound_handoff_buffer_tracks_every_frame(tmp_path, oracle_mod):
     """The interactive loop (main.cpp:3563-3618: one RenderFrame(), one glTexSubImage2D(texData)): SetOutImage binds the
-    caller's buffer (ptk_bind_out_image) and the accumulate kernel's 8-bit resolve lands in it directly - an ordinary
-    `new GLubyte[]`-like buffer is page-locked in place, a ptk_host_alloc one used as it is.  Whatever happens between
+    caller's buffer: a ptk_host_alloc one is bound (ptk_bind_out_image) and the accumulate kernel's 8-bit resolve lands in it
+    directly, an ordinary `new GLubyte[]`-like buffer is left alone and receives a copy of the frame.  Whatever happens between
     frames - camera moves that change which pixels are black for good, ResetImage, an Exit(), a new resolution - the
     buffer holds exactly the device's resolved frame (and the oracle's) after every RenderFrame()."""
     from pbrpathtracer_amd import scenes as S
@@ -316,7 +316,7 @@ def test_bound_handoff_buffer_tracks_every_frame(tmp_path, oracle_mod):
     for pinned in (False, True):
         pt = PathTracer(0); pt.LoadSceneFile(pts); pt.SetSeed(9); pt.SetCameraAperture(0.0)
         W, H = pt.GetResolution()
-        out = pt.AllocOutImage() if pinned else np.full((H, W, 3), 77, np.uint8)       # (garbage in: the bind clears it)
+        out = pt.AllocOutImage() if pinned else np.full((H, W, 3), 77, np.uint8)       # (garbage in: every frame overwrites it whole)
         pt.SetOutImage(out)
         ctx = None
         for frame in range(12):
@@ -345,14 +345,11 @@ def test_bound_handoff_buffer_tracks_every_frame(tmp_path, oracle_mod):
         pt.SetResolution((64, 48))
         out2 = np.full((48, 64, 3), 5, np.uint8)
         if not pinned:
-            # the caller's buffer is page-locked in place while bound - and let go by SetOutImage ITSELF, not at the next render:
-            # main.cpp:3433-3445 frees texData right around that call, and memory freed while still registered poisons whatever
-            # the allocator puts there next (found by tools/soak_api.py)
+            # ordinary memory is NEVER registered with the runtime (round 3 page-locked it in place; the viewer frees texData before
+            # it hands over the next buffer and at exit without a word, main.cpp:3433-3445, :3622 - ADVICE r03): the frame is copied
             import ctypes
             hip = ctypes.CDLL("libamdhip64.so"); dev_alias = ctypes.c_void_p(0)
-            assert hip.hipHostGetDevicePointer(ctypes.byref(dev_alias), ctypes.c_void_p(out.ctypes.data), 0) == 0     # registered now
-            pt.SetOutImage(out2)
-            assert hip.hipHostGetDevicePointer(ctypes.byref(dev_alias), ctypes.c_void_p(out.ctypes.data), 0) != 0     # ... and not any more
+            assert hip.hipHostGetDevicePointer(ctypes.byref(dev_alias), ctypes.c_void_p(out.ctypes.data), 0) != 0
             hip.hipGetLastError()
         pt.SetOutImage(out2); pt.ResetImage(); pt.RenderFrame()
         dev2 = np.zeros((48, 64, 3), np.uint8); ctx = pt.context(); ctx.L.ptk_resolve_rgb8(ctx.h, dev2.ctypes.data)
