@@ -134,6 +134,9 @@ __device__ __forceinline__ float rcp_ieee_any(float a)
 #ifndef PTK_NODE_PREFETCH
 #define PTK_NODE_PREFETCH 1
 #endif
+#ifndef PTK_FLAT_SHARED_ORIGIN
+#define PTK_FLAT_SHARED_ORIGIN 1    // FLAT pass: the origin-only part of Moeller-Trumbore once per lane, not once per ray
+#endif
 #ifndef PTK_TRI_PER_EXEC
 #define PTK_TRI_PER_EXEC 2          // triangles one execution of walk_step's (voted) triangle arm tests per lane
 #endif
@@ -400,12 +403,24 @@ __device__ __forceinline__ bool tri_test_pair(const PT& P, Walk& W, Walk& WS, co
     const f2 hx = R.dy * e2z - R.dz * e2y, hy = R.dz * e2x - R.dx * e2z, hz = R.dx * e2y - R.dy * e2x;
     const f2 a = hx * e1x + hy * e1y + hz * e1z;                 // dot(edge1, h)
     const f2 f = { rcp_ieee(a.x), rcp_ieee(a.y) };
+#if PTK_FLAT_SHARED_ORIGIN
+    // The two rays of a lane leave the SAME point (shade_interaction starts both at p), so everything of Moeller-Trumbore that
+    // depends on the origin alone - s = ro - v0, q = cross(s, edge1), dot(edge2, q) - is the same number for both: computed once
+    // in scalar f32 (full rate) instead of twice in packed f32 (half rate), 17 of the ~60 operations per ray and triangle.  The
+    // same IEEE operations on the same inputs: bit-identical.  (No shadow ray: its half of the packed values is ignored anyway.)
+    const float sx = W.ro.x - v0x, sy = W.ro.y - v0y, sz = W.ro.z - v0z;      // s = ro - v0
+    const f2 u = f * (sx * hx + sy * hy + sz * hz);
+    const float qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;      // q = cross(s, edge1)
+    const f2 v = f * (R.dx * qx + R.dy * qy + R.dz * qz);
+    const f2 t = f * (qx * e2x + qy * e2y + qz * e2z);
+#else
     const f2 sx = R.ox - v0x, sy = R.oy - v0y, sz = R.oz - v0z;  // s = ro - v0
     const f2 u = f * (sx * hx + sy * hy + sz * hz);
     // q = cross(s, edge1)
     const f2 qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;
     const f2 v = f * (R.dx * qx + R.dy * qy + R.dz * qz);
     const f2 t = f * (qx * e2x + qy * e2y + qz * e2z);
+#endif
     const f2 uv = u + v;
     const int tri = __float_as_int(t2.y);
     const int otex = __float_as_int(t2.z);
@@ -490,7 +505,7 @@ __device__ __forceinline__ void request_node(const PT& P, const Walk& W, NodeRec
 // loop or at the end of the lane's previous step, and the record of the node this step ends on is requested before the step
 // returns, so its round trip also covers the loop's wave-uniform bookkeeping (ballots, debts, ~30 dependent scalar instructions)
 // instead of starting behind it.
-template <bool STATS, int STRIDE, bool PIPELINED = false, class PT>
+template <bool STATS, int STRIDE, bool PIPELINED = false, int TRI_PER_EXEC = PTK_TRI_PER_EXEC, class PT>
 __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, uint32_t ray, int* stack, Counters& cnt,
                                           const bool run_tri_arm = true, NodeRec* rec = nullptr)
 {
@@ -503,8 +518,7 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
     asm volatile("" ::: "memory");
 #endif
     const bool node_was = W.node >= 0;
-#if PTK_TRI_PER_EXEC == 2
-    if (run_tri_arm && W.tri_left > 0)                    // ---- arm A: up to TWO triangles
+    if (TRI_PER_EXEC == 2 && run_tri_arm && W.tri_left > 0)       // ---- arm A: up to TWO triangles
     {
         // The second triangle: the pending leaf's next one, or - the pending leaf has only this one left and the lane is BLOCKED
         // on a second leaf (W.node holds it: the one-leaf queue was busy) - the first triangle of that leaf, whose remainder then
@@ -533,8 +547,7 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
         W.tri_left = stop ? 0 : W.tri_left;
         W.node = stop ? NODE_EXIT : W.node;
     }
-#else
-    if (run_tri_arm && W.tri_left > 0)                    // ---- arm A: one triangle
+    if (TRI_PER_EXEC != 2 && run_tri_arm && W.tri_left > 0)       // ---- arm A: one triangle
     {
         const float4* tp = (const float4*)((const char*)P.tris + (uint32_t)W.tri_next * (uint32_t)(TRI_F4 * 16));
         float4 t0 = ldg4(tp), t1 = ldg4(tp + 1), t2 = ldg4(tp + 2);
@@ -544,7 +557,6 @@ __device__ __forceinline__ void walk_step(const PT& P, Walk& W, const Rng& rng, 
         W.tri_left = stop ? 0 : W.tri_left;
         W.node = stop ? NODE_EXIT : W.node;
     }
-#endif
     if (node_was && W.node >= 0)                          // ---- arm B: one 4-wide interior node (its record is `here`; a node popped by arm A waits a step)
     {
 #if !PTK_NODE_PREFETCH
@@ -1687,7 +1699,7 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES_BVH) void trace_po
                     if (STATS && lane == 0 && run_tri_arm) { cnt.tri_execs++; cnt.tri_lanes += (uint32_t)n_tq; }
                     if (jst == J_WALK)
                     {
-                        walk_step<STATS, PTK_TRACE_BLOCK>(WP, W, rng, ray, stack, cnt, run_tri_arm);
+                        walk_step<STATS, PTK_TRACE_BLOCK, false, 1>(WP, W, rng, ray, stack, cnt, run_tri_arm);      // (one triangle per execution: the pooled kernel has no registers to spare)
                         if (W.done())
                         {
                             if (STATS) { cnt.rays++; cnt.max_nodes = max(cnt.max_nodes, cnt.cur_nodes); cnt.cur_nodes = 0; }

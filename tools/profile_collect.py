@@ -1,6 +1,15 @@
-"""Turn the raw output of tools/profile_round.sh (gpurun_out/<dir>) into the tracked summaries under profiles/<dir>.
+"""Turn the raw output of tools/profile_round.sh (gpurun_out/prof_<round>) into the tracked summaries under profiles/<round>.
 
-    python tools/profile_collect.py gpurun_out/r01b profiles/r01_final
+    python tools/profile_collect.py gpurun_out/prof_r04 profiles/r04
+
+Writes (whatever the raw directory holds):
+  bench_C{1..5}.json                          the bench lines
+  rocprofv3_kernel_stats_C{2,4}.csv           per-kernel time of `bench.py --opts overlap=0` (launches not overlapped)
+  traffic_C{2..5}.json (+ ../traffic_Cn.json) HBM bytes per trace_kernel launch: FETCH_SIZE x2 (gfx950: 128-B requests tallied
+                                              at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, and the L2 hit rate TCC_HIT / (HIT + MISS)
+  pmc_sq_trace_kernel_C{2,4,5}.json           SQ counters of the full-size launches + the instruction-class counters + the issue
+                                              cycles they imply with the measured per-class costs (valu_calibration.json)
+  pmc_mem_trace_kernel_C{4,5}.json            TA / TCP / TD counters: how busy the vector-memory (gather) path is
 """
 import collections
 import csv
@@ -12,10 +21,28 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import hashlib
+
+
+def kernel_source_sha256():
+    """the counter files are tied to the kernel sources they were collected for (bench.py ignores them once these change)"""
+    f = os.path.join(src, "kernel_source_sha256.txt")          # written on the GPU box by profile_round.sh from the sources that ran
+    if os.path.exists(f):
+        return open(f).read().strip()
+    h = hashlib.sha256()
+    for n in ("ptk_kernels.hip", "ptk_device.h"):
+        h.update(open(os.path.join(ROOT, "pbrpathtracer_amd", "csrc", n), "rb").read())
+    return h.hexdigest()
+
+
+SHA = kernel_source_sha256()
+TRACE = "trace_kernel<false"
 
 
 def dispatches(d, kernel_substr):
-    """{dispatch id: {counter: value, ms, grid}} of the kernels whose name contains kernel_substr."""
+    """one dict per dispatch of the kernels whose name contains kernel_substr: {counter: value, ms, grid, kernel}"""
     per = collections.defaultdict(dict)
     for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -23,7 +50,7 @@ def dispatches(d, kernel_substr):
                 e = per[(f, r["Dispatch_Id"])]
                 e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                 e["ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-                e["grid"] = int(r["Grid_Size"]); e["kernel"] = r["Kernel_Name"]
+                e["grid"] = int(r["Grid_Size"]); e["kernel"] = r["Kernel_Name"]; e["vgpr"] = r.get("VGPR_Count")
     return list(per.values())
 
 
@@ -36,57 +63,148 @@ def full_launches(ds):
     return [x for x in ds if x["ms"] >= 0.5 * longest]
 
 
+def mean_of(ds, key):
+    v = [x[key] for x in ds if key in x]
+    return sum(v) / len(v) if v else None
+
+
+bench = {}
 for c in ("C1", "C2", "C3", "C4", "C5"):
     f = os.path.join(src, f"bench_{c}.json")
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, f"bench_{c}.json"))
-for f in glob.glob(f"{src}/ktrace/**/*_kernel_stats.csv", recursive=True):
-    shutil.copy(f, os.path.join(dst, "rocprofv3_kernel_stats_bench_C2.csv"))
-
-# HBM traffic of the headline config: FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE, KiB units
-tr = {}
-for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    for kern, key in (("trace_kernel<false", "trace"), ("accumulate_kernel", "accumulate")):
-        ds = full_launches(dispatches(os.path.join(src, sub), kern))
-        if ds:
-            tr[(key, name)] = sum(x[name] for x in ds) / len(ds)
-            tr[(key, "ms")] = sum(x["ms"] for x in ds) / len(ds)
-            tr[(key, "n")] = len(ds)
-            tr[(key, "kernel")] = ds[0]["kernel"]
-if ("trace", "FETCH_SIZE") in tr and ("trace", "WRITE_SIZE") in tr:
-    out = {
-        "config": "C2", "spp": 256, "n_gpus": 1, "kernel": tr[("trace", "kernel")],
-        "hbm_bytes_per_launch": int((2 * tr[("trace", "FETCH_SIZE")] + tr[("trace", "WRITE_SIZE")]) * 1024),
-        "fetch_size_kib": tr[("trace", "FETCH_SIZE")], "write_size_kib": tr[("trace", "WRITE_SIZE")],
-        "launches_averaged": tr[("trace", "n")], "kernel_ms_under_profiler": tr[("trace", "ms")],
-        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 3 --warmup 1 "
-                  "--no-cpu-baseline`; FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B), WRITE_SIZE as read",
-        "accumulate_kernel": {"FETCH_SIZE_KiB": tr.get(("accumulate", "FETCH_SIZE")), "WRITE_SIZE_KiB": tr.get(("accumulate", "WRITE_SIZE")),
-                              "ms": tr.get(("accumulate", "ms")), "launches": tr.get(("accumulate", "n"))},
-    }
-    json.dump(out, open(os.path.join(dst, "pmc_hbm_traffic_C2.json"), "w"), indent=1)
-    json.dump(out, open(os.path.join(os.path.dirname(dst.rstrip("/")), "traffic_C2.json"), "w"), indent=1)
-    print("traffic", out["hbm_bytes_per_launch"] / 1e9, "GB per launch")
-
-# SQ counters of the full-size trace_kernel launches
+        try:
+            bench[c] = json.load(open(f))
+        except Exception:
+            pass
 for c in ("C2", "C4"):
-    merged = {}
-    for p in sorted(glob.glob(os.path.join(src, f"sq_{c}", "p*"))):
-        ds = full_launches(dispatches(p, "trace_kernel<false"))
+    for f in glob.glob(f"{src}/ktrace_{c}/**/*_kernel_stats.csv", recursive=True):
+        shutil.copy(f, os.path.join(dst, f"rocprofv3_kernel_stats_{c}.csv"))
+
+# the DEFAULT (overlap = 1) C2 run: start / end of consecutive trace_kernel launches - how much of a launch's tail the next
+# launch covers, i.e. why ms_per_step < the isolated kernel time
+rows = []
+for f in glob.glob(f"{src}/ktrace_overlap_C2/**/*_kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if TRACE in r["Kernel_Name"]:
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+rows.sort()
+if len(rows) > 8:
+    durs = [(e - s) / 1e6 for s, e in rows]
+    med = sorted(durs)[len(durs) // 2]
+    full = [(s, e) for (s, e), d in zip(rows, durs) if d >= 0.5 * med]      # (not the 1-spp set-up launch)
+    pairs = []
+    for (s0, e0), (s1, e1) in zip(full[:-1], full[1:]):
+        pairs.append({"launch_ms": round((e0 - s0) / 1e6, 4), "next_start_after_this_start_ms": round((s1 - s0) / 1e6, 4),
+                      "overlap_ms": round(max(0, e0 - s1) / 1e6, 4)})
+    # steady state: the timed loop's launches (the first ones still share the chip with the warm-up; the last three are
+    # bench.py's isolated launches, overlap = 0, which start after their predecessor has ended)
+    steady = [p for p in pairs[len(pairs) // 4:] if p["overlap_ms"] > 0.0 and p["launch_ms"] < 1.5 * med]
+    ov = {"command": "rocprofv3 --kernel-trace -- python3 bench.py --config C2 --steps 40 --warmup 5 --no-cpu-baseline --no-other-configs --no-parity --no-contracted --no-interactive   (overlap option at its default, 1)",
+          "kernel": "trace_kernel<false, true>", "full_launches": len(full),
+          "mean_launch_ms": round(sum(p["launch_ms"] for p in steady) / len(steady), 4),
+          "mean_start_to_start_ms": round(sum(p["next_start_after_this_start_ms"] for p in steady) / len(steady), 4),
+          "mean_overlap_ms": round(sum(p["overlap_ms"] for p in steady) / len(steady), 4),
+          "note": "consecutive launches alternate between two streams; launch k+1 starts while launch k's last waves (its longest paths) are still running: "
+                  "start-to-start (= ms_per_step) is shorter than a launch by the mean overlap", "kernel_source_sha256": SHA, "pairs_head": pairs[:12]}
+    json.dump(ov, open(os.path.join(dst, "overlap_trace_C2.json"), "w"), indent=1)
+    print("overlap C2:", {k: v for k, v in ov.items() if k.startswith("mean") or k == "full_launches"})
+for name in ("valu_calibration.json", "gather_ceiling.json", "exact_math.json"):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, name))
+
+SPP = {"C1": 16, "C2": 256, "C3": 512, "C4": 256, "C5": 1024}
+for c in ("C2", "C3", "C4", "C5"):
+    base = os.path.join(src, f"traffic_{c}")
+    if not os.path.isdir(base):
+        continue
+    ds = {n: full_launches(dispatches(os.path.join(base, p), TRACE)) for n, p in (("fetch", "p1"), ("write", "p2"), ("tcc", "p3"))}
+    if not ds["fetch"] or not ds["write"]:
+        continue
+    fetch, write = mean_of(ds["fetch"], "FETCH_SIZE"), mean_of(ds["write"], "WRITE_SIZE")
+    hit, miss = mean_of(ds["tcc"], "TCC_HIT_sum"), mean_of(ds["tcc"], "TCC_MISS_sum")
+    acc = {n: full_launches(dispatches(os.path.join(base, p), "accumulate_kernel")) for n, p in (("fetch", "p1"), ("write", "p2"))}
+    out = {
+        "config": c, "spp": SPP[c], "n_gpus": 1, "kernel": ds["fetch"][0]["kernel"], "kernel_source_sha256": SHA,
+        "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
+        "fetch_size_kib": fetch, "write_size_kib": write,
+        "launches_averaged": len(ds["fetch"]), "kernel_ms_under_profiler": mean_of(ds["fetch"], "ms"),
+        "hbm_GBps": (2 * fetch + write) * 1024 / (mean_of(ds["fetch"], "ms") * 1e-3) / 1e9,
+        "cache": None if hit is None else {"TCC_HIT": hit, "TCC_MISS": miss, "l2_hit_rate": hit / max(1.0, hit + miss),
+                                            "TCC_REQ": mean_of(ds["tcc"], "TCC_REQ_sum"), "TCC_READ": mean_of(ds["tcc"], "TCC_READ_sum"),
+                                            "note": "L2 (TCC) requests of one launch, summed over the 8 XCDs; what misses goes to the Infinity Cache / HBM (FETCH_SIZE)"},
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum (three separate passes) on "
+                  "`python3 bench.py --config %s --no-cpu-baseline --no-other-configs --opts overlap=0`; FETCH_SIZE x2 per MI355X_MICROARCH.md "
+                  "(gfx950 counts 128-B requests as 64 B), WRITE_SIZE as read" % c,
+        "accumulate_kernel": {"FETCH_SIZE_KiB": mean_of(acc["fetch"], "FETCH_SIZE"), "WRITE_SIZE_KiB": mean_of(acc["write"], "WRITE_SIZE"),
+                              "ms": mean_of(acc["fetch"], "ms")},
+    }
+    json.dump(out, open(os.path.join(dst, f"traffic_{c}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(os.path.dirname(dst.rstrip("/")), f"traffic_{c}.json"), "w"), indent=1)
+    print(c, "traffic %.3f GB per launch, %.1f GB/s, L2 hit %.3f" % (out["hbm_bytes_per_launch"] / 1e9, out["hbm_GBps"],
+                                                                   out["cache"]["l2_hit_rate"] if out["cache"] else -1))
+
+# measured issue cost per instruction class (cycles a SIMD spends per wave-instruction, 4 waves per SIMD)
+cal = {}
+cf = os.path.join(dst, "valu_calibration.json")
+if not os.path.exists(cf):
+    cf = os.path.join(ROOT, "profiles", "r02", "valu_calibration.json")      # the calibration microbenchmark of round 2 (hardware, not kernels)
+if os.path.exists(cf):
+    for r in json.load(open(cf))["rows"]:
+        cal[r["op"]] = r["w4"]["cyc"]
+
+
+def merge(base, passes, kern=TRACE):
+    m = {}
+    for p in sorted(glob.glob(os.path.join(base, passes))):
+        ds = full_launches(dispatches(p, kern))
         for k in (ds[0] if ds else {}):
-            if k not in ("grid", "kernel"):
-                merged[k] = sum(x[k] for x in ds) / len(ds)
+            if k not in ("grid", "kernel", "vgpr"):
+                m[k] = sum(x[k] for x in ds) / len(ds)
         if ds:
-            merged["kernel"] = ds[0]["kernel"]; merged["grid_threads"] = ds[0]["grid"]
-    if "SQ_INSTS_VALU" in merged:
-        m = merged
-        m["lane_utilisation"] = m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_INSTS_VALU"])
-        m["wave_life_in_s_waitcnt"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
-        m["wave_life_issuing_valu"] = m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"]
-        m["wave_life_waiting_to_issue"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
-        m["avg_waves_per_simd"] = m["SQ_WAVE_CYCLES"] * 4 / (m["ms"] * 1e-3 * 2.4e9) / 1024
-        m["valu_pipe_busy"] = min(1.0, m["wave_life_issuing_valu"] * m["avg_waves_per_simd"])
-        m["clock_assumed_GHz"] = 2.4        # avg_waves_per_simd and valu_pipe_busy scale with it (the chip clocks lower under load)
-        m["units"] = "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are in quad-cycles summed over waves; ms is the kernel time under the profiler"
-        json.dump(m, open(os.path.join(dst, f"pmc_sq_trace_kernel_{c}.json"), "w"), indent=1)
-        print(c, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in m.items() if k[0].islower()})
+            m["kernel"] = ds[0]["kernel"]; m["grid_threads"] = ds[0]["grid"]; m["vgpr"] = ds[0]["vgpr"]
+    return m
+
+
+for c in ("C2", "C4", "C5"):
+    m = merge(os.path.join(src, f"sq_{c}"), "p*")
+    if "SQ_INSTS_VALU" not in m:
+        continue
+    cl = merge(os.path.join(src, f"class_{c}"), "p*")
+    m["lane_utilisation"] = m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_INSTS_VALU"])
+    m["wave_life_in_s_waitcnt"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
+    m["wave_life_waiting_to_issue"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
+    # SQ_BUSY_CYCLES counts per shader engine (32 of them) in cycles: its mean over the launch gives the clock the chip held
+    m["clock_GHz_from_SQ_BUSY_CYCLES"] = m["SQ_BUSY_CYCLES"] / 32.0 / (m["ms"] * 1e-3) / 1e9
+    clock = m["clock_GHz_from_SQ_BUSY_CYCLES"] if 1.0 < m["clock_GHz_from_SQ_BUSY_CYCLES"] < 2.6 else 2.1
+    simd_cycles = 1024 * clock * 1e9 * m["ms"] * 1e-3                 # issue cycles available: 256 CUs x 4 SIMDs
+    m["avg_waves_per_simd"] = m["SQ_WAVE_CYCLES"] * 4 / simd_cycles
+    # calibrated issue cycles: SQ_ACTIVE_INST_VALU charges one quad-cycle to every non-transcendental instruction, whatever it
+    # costs the pipe (profiles/r02/valu_calibration.json: v_fma/v_mul/v_add/v_mov/logic ~2.4 cycles, v_cmp/v_cndmask/v_min/v_max/
+    # cvt/v_mul_lo/packed f32/f64 ~4.3, transcendental ~8.2), so the pipe's occupancy is bounded from the class counters instead
+    if cl and cal:
+        full = sum(cl.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"))
+        trans = cl.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+        rest = max(0.0, m["SQ_INSTS_VALU"] - full - trans)
+        lo = full * cal["fma"] + trans * cal["rcp"] + rest * cal["xor"]           # everything else at the full rate
+        hi = full * cal["pk_mul"] + trans * cal["rcp"] + rest * cal["cmp"]        # packed forms of add/mul, everything else half rate
+        m["classes"] = {k: v for k, v in cl.items() if k.startswith("SQ_INSTS")}
+        m["valu_issue_cycles_used_low"] = lo; m["valu_issue_cycles_used_high"] = hi
+        m["valu_pipe_busy_low"] = lo / simd_cycles; m["valu_pipe_busy_high"] = hi / simd_cycles
+        m["valu_pipe_busy_note"] = ("issue cycles used / available (1024 SIMDs x clock x kernel time).  low: add/mul/fma f32 counted at the "
+                                    "scalar full-rate cost and every other non-transcendental instruction at the full rate too; high: add/mul "
+                                    "counted as packed (v_pk_*, half rate per instruction) and every other instruction (compares, selects, "
+                                    "min/max, conversions, integer multiplies, f64) at the measured half rate.  The truth lies between; the "
+                                    "kernels' compares / selects / conversions put it near the high figure.")
+    m["kernel_source_sha256"] = SHA
+    m["units"] = "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are in quad-cycles summed over waves; ms is the kernel time under the profiler"
+    json.dump(m, open(os.path.join(dst, f"pmc_sq_trace_kernel_{c}.json"), "w"), indent=1)
+    print(c, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in m.items() if k[0].islower() and k not in ("classes", "valu_pipe_busy_note", "units", "kernel")})
+
+for c in ("C4", "C5"):
+    m = merge(os.path.join(src, f"mem_{c}"), "p*")
+    if not m:
+        continue
+    json.dump(m, open(os.path.join(dst, f"pmc_mem_trace_kernel_{c}.json"), "w"), indent=1)
+    print(c, "mem", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in m.items() if k not in ("kernel",)})
