@@ -7,6 +7,23 @@
 // does (grey -> g,g,g,255; 16-bit -> high byte).  Images with a side > 1024 are reduced so the
 // longest side is 1024 (image.cpp:47-60) with stb_image_resize's default downsampling (Mitchell kernel,
 // clamped edges), bit-identically (tests/golden/tier_k_resize.npz).
+//
+// PROVENANCE: this file is NOT written from scratch in the sense the kernels are.  The reference decodes its
+// textures with the vendored stb_image 2.27 / stb_image_resize (include/stb_image.h, include/stb_image_resize.h in the reference
+// tree; both public domain / MIT, Sean Barrett et al.), and a texel that differs by one bit changes a nearest-texel lookup and
+// with it a material branch - so the decoders here reproduce stb_image's FIXED-POINT ARITHMETIC AND TABLE CONSTRUCTION exactly,
+// and the following blocks are condensed restatements of its routines, several of its identifiers kept so that the two can be
+// read side by side:
+//   * JPEG: the Huffman table build (JpegHuff::build <- stbi__build_huffman, stb_image.h:2052-2068), the bit-buffer refill and
+//     extend-receive (grow / extend_receive <- stbi__grow_buffer_unsafe / stbi__extend_receive), the integer IDCT (JIDCT_1D <-
+//     STBI__IDCT_1D, :2396-2431, its t0..t3 / p1..p5 / x0..x3 temporaries), the progressive-scan refinement and the YCbCr /
+//     upsampling fixed-point constants;
+//   * GIF: the LZW code loop (codesize / codemask / avail / oldcode / valid_bits <- stbi__process_gif_raster, :6613-6690);
+//   * PSD / PIC / PNM / HDR / TGA / BMP: the header checks and refusal rules in stb_image's order (so that a file it refuses yields
+//     no texture here either);
+//   * the > 1024 px reduction: stb_image_resize's Mitchell filter footprint and float accumulation order.
+// Everything else (file handling, PNG through zlib with its own un-filter, the 4-channel expansion, the class wrapper) is this
+// repository's.  The file is host-side ingest, off the render path, FROZEN since round 3 apart from safety fixes.
 #include <zlib.h>
 
 #include <algorithm>

@@ -129,7 +129,7 @@ struct ptk_ctx {
     int opt_max_batch = 1;                       // slots a persistent wave pops from its queue at once; > 1 measured slower everywhere
     int opt_device_build = 1;                    // scenes of >= 4096 triangles: BVH built and records packed on the GPU (bvh_device.hip)
     bool built_on_device = false;
-    int opt_tri_thr = 4;                         // triangle arm of the walk runs when queued lanes >= tri_thr/8 x walking lanes
+    int opt_tri_thr = 6;                         // triangle arm of the walk runs when queued lanes >= tri_thr/8 x walking lanes
     int opt_shade_thr = 0, opt_gen_thr = 16;     // scheduling lambdas in eighths, see trace_kernel; 0 = by tree depth
     size_t opt_pass_bytes = (size_t)16 << 30;    // sample-buffer budget per pass (two such buffers at most, of the 288 GB: C4 traces its 256 spp in one launch, C5 its 1024 in two: +0.4 / +1.2 % over 4 GiB)
 
