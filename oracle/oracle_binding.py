@@ -45,8 +45,23 @@ class CameraC(C.Structure):
                 ("aperture", C.c_float)]
 
 
-def make_camera(pos, dir, up, focal, fovy, focal_dist, aperture) -> CameraC:
+def glm_normalize(v) -> np.ndarray:
+    """glm::normalize in float32, operation by operation: x * (1 / sqrt(x.x + y.y + z.z)) - what PathTracer::SetCamera does to
+    dir and up (pathtracer.cpp:336-337) and ptk_set_camera repeats."""
+    x = np.asarray(v, np.float32)
+    sqr = np.float32(np.float32(np.float32(x[0] * x[0]) + np.float32(x[1] * x[1])) + np.float32(x[2] * x[2]))
+    inv = np.float32(np.float32(1.0) / np.float32(np.sqrt(sqr)))
+    return np.array([np.float32(x[0] * inv), np.float32(x[1] * inv), np.float32(x[2] * inv)], np.float32)
+
+
+def make_camera(pos, dir, up, focal, fovy, focal_dist, aperture, normalise: bool = False) -> CameraC:
+    """The camera as it stands AFTER the reference's setters.  `dir` and `up` are taken as given - fixtures store what
+    SetCamera left - unless normalise=True: then they are put through SetCamera's own normalisation (pathtracer.cpp:336-337),
+    for callers that hand the same RAW vectors to ptk_set_camera, which normalises them the same way (normalising twice is not
+    always a no-op in float32: tools/soak_lens_cull.py found cameras whose every primary direction differed in the last bit)."""
     c = CameraC()
+    if normalise:
+        dir, up = glm_normalize(dir), glm_normalize(up)
     c.pos[:] = [float(x) for x in pos]
     c.dir[:] = [float(x) for x in dir]
     c.up[:] = [float(x) for x in up]

@@ -137,8 +137,12 @@ def _load_locked() -> C.CDLL:
     L.ptk_last_kernel_ms.argtypes = [vp, fp, fp]
     L.ptk_set_option.argtypes = [vp, C.c_char_p, C.c_double]
     L.ptk_collect_stats.argtypes = [vp, u32, u32, u64, C.POINTER(Stats)]
-    L.ptk_kernel_log.argtypes = [vp, i32]
-    L.ptk_kernel_log_read.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]
+    try:
+        L.ptk_kernel_log.argtypes = [vp, i32]
+        L.ptk_kernel_log_read.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]
+    except AttributeError:
+        if LIB_PATH.endswith("libptk.so"):      # (an older build loaded through PTK_DEV_TOOLS for an A/B may lack the newest entry points)
+            raise
     L.ptk_bvh_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ptk_bvh_layout.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ptk_download_bvh.argtypes = [vp, vp, vp]

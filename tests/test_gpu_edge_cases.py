@@ -195,3 +195,92 @@ def test_work_distribution_modes_agree(ctx, oracle_mod, golden, aperture):
     ctx.set_tile(0, 1)
     for k, v in defaults.items():
         ctx.set_option(k, v)
+
+
+def test_bound_handoff_buffer_follows_another_accumulator_and_other_tiles(ctx, oracle_mod):
+    """with a hand-off buffer bound, pixels that are black for every sample are skipped by the accumulate kernel unless the
+    next frame is marked 'write everything'.  Switching to ANOTHER accumulator (ptk_bind_accum) or to other tiles (ptk_set_tile)
+    must set that mark: the skipped pixels hold light in the old accumulator's frame that the new one does not have."""
+    import torch
+    from pbrpathtracer_amd import ptk
+    z = load_golden("tier_s_cornell.npz")
+    arrays = scene_from_golden(z); cam = _cam(z, aperture=0.0)
+    W, H = 96, 64
+    ctx.upload_scene(arrays); ctx.set_camera(**cam); ctx.set_frame(W, H, 3); ctx.set_tile(0, 1); ctx.reset()
+    raw = ptk.load().ptk_host_alloc(W * H * 3)
+    import ctypes as C
+    out = np.ctypeslib.as_array(C.cast(raw, C.POINTER(C.c_uint8)), shape=(H, W, 3))
+    try:
+        ctx.bind_out_image(out)
+        ctx.render(0, 2, 9); ctx.resolve_rgb8(out)
+        # a camera move without a reset: pixels that now miss the box still hold light in the accumulator (they keep dimming)
+        cam2 = dict(cam); cam2["pos"] = np.array(cam["pos"], np.float32) + np.array([0.8, 0.3, 0.0], np.float32)
+        ctx.set_camera(**cam2); ctx.render(2, 2, 9); ctx.resolve_rgb8(out)
+        dev = np.zeros((H, W, 3), np.uint8); ctx.L.ptk_resolve_rgb8(ctx.h, dev.ctypes.data)
+        assert np.array_equal(out, dev)
+        # another, zeroed accumulator: the frame is now only the NEW accumulator's - every pixel of the bound buffer must follow
+        other = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda:0"); torch.cuda.synchronize()
+        ctx.bind_accum(other.data_ptr())
+        ctx.render(4, 1, 9); ctx.resolve_rgb8(out)
+        ctx.L.ptk_resolve_rgb8(ctx.h, dev.ctypes.data)
+        assert np.array_equal(out, dev)
+        ctx.bind_accum(None)
+        # other tiles: rank 1 of 2 after rank 0 of 2 (the accumulator keeps what rank 0's tiles hold; the frame shows both)
+        ctx.reset(); ctx.set_tile(0, 2); ctx.render(0, 1, 9); ctx.resolve_rgb8(out)
+        ctx.set_tile(1, 2); ctx.render(0, 1, 9); ctx.resolve_rgb8(out)
+        ctx.L.ptk_resolve_rgb8(ctx.h, dev.ctypes.data)
+        assert np.array_equal(out, dev) and out.any()
+    finally:
+        ctx.set_tile(0, 1); ctx.bind_accum(None); ctx.bind_out_image(None)
+        ptk.load().ptk_host_free(raw)
+
+
+def test_render_takes_more_passes_when_device_memory_is_short(oracle_mod):
+    """the sample-buffer budget is 16 GiB per pass; on a GPU whose memory is mostly taken (a framework sharing it, a huge
+    scene) a render must fall back to smaller passes instead of failing with an allocation error.  Most of the free memory is
+    taken away with one torch allocation; a 1920 x 1080 render of 192 spp then needs more passes - and gives the image of the same
+    samples rendered in comfortable 32-spp calls, bit for bit."""
+    import torch
+    from pbrpathtracer_amd import ptk
+    z = load_golden("tier_s_cornell.npz")
+    arrays = scene_from_golden(z); cam = _cam(z, aperture=0.0)
+    c = ptk.Context(0)
+    hog = None
+    try:
+        W, H = 1920, 1080
+        c.upload_scene(arrays); c.set_camera(**cam); c.set_frame(W, H, 3); c.set_tile(0, 1); c.reset()
+        for k in range(6):
+            c.render(32 * k, 32, 3)
+        want = c.read_accum()
+        free, total = torch.cuda.mem_get_info(0)
+        keep = 5 << 30                                   # leave ~5 GiB: 192 spp x 2 M pixels x 16 B = 6.4 GB per buffer, two of them, will not fit
+        hog = torch.empty(max(0, free - keep), dtype=torch.uint8, device="cuda:0"); torch.cuda.synchronize()
+        c.reset(); c.render(0, 192, 3)
+        got = c.read_accum()
+        ms, launches = c.last_render_ms()
+        assert launches > 3                               # more than one pass (3 launches each)
+        assert np.array_equal(got, want)
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+        c.close()
+
+
+def test_kernel_log_times_every_trace_launch(ctx):
+    """ptk_kernel_log / ptk_kernel_log_read (bench.py's per-launch durations inside its timed region): one entry per trace launch,
+    in order, overlapped renders included; reading empties the log; capacity bounds it."""
+    z = load_golden("tier_s_cornell.npz")
+    arrays = scene_from_golden(z); cam = _cam(z, aperture=0.0)
+    ctx.upload_scene(arrays); ctx.set_camera(**cam); ctx.set_frame(128, 96, 3); ctx.set_tile(0, 1); ctx.reset()
+    ctx.kernel_log(8)
+    for k in range(5):
+        ctx.render(4 * k, 4, 1)
+    ms = ctx.kernel_log_read()
+    assert len(ms) == 5 and all(0.0 < m < 1000.0 for m in ms)
+    assert ctx.kernel_log_read() == []
+    for k in range(11):
+        ctx.render(20 + k, 1, 1)
+    assert len(ctx.kernel_log_read()) == 8               # the log holds `capacity` launches
+    ctx.kernel_log(0)
+    ctx.render(40, 1, 1)
+    assert ctx.kernel_log_read() == []

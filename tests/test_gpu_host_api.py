@@ -148,8 +148,7 @@ def test_lens_cull_is_exact(tmp_path, oracle_mod, cfg, kw, spp, aperture):
         if move is not None:
             pt.SetCamera(move[0], move[1], (0, 1, 0)); pt.ResetImage()
             cam["pos"] = np.array(move[0], np.float32)
-            d = np.array(move[1], np.float32); cam["dir"] = d / np.float32(np.sqrt((d * d).sum(dtype=np.float32)))
-            cam["up"] = np.array([0, 1, 0], np.float32)
+            cam["dir"] = np.array(move[1], np.float32); cam["up"] = np.array([0, 1, 0], np.float32)      # raw, as SetCamera gets them
         ctx = pt.context(); ctx.set_option("lens_cull", 1)
         pt.RenderFrames(spp)
         assert pt.LastError() == ""
@@ -161,7 +160,7 @@ def test_lens_cull_is_exact(tmp_path, oracle_mod, cfg, kw, spp, aperture):
         st0 = ctx.collect_stats(0, spp, 33)
         assert st0["paths_started"] == st0["samples"]                      # every pixel traced without the cull
         assert np.array_equal(culled, plain), move
-        ocam = oracle_mod.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"])
+        ocam = oracle_mod.make_camera(cam["pos"], cam["dir"], cam["up"], cam["focal"], cam["fovy"], cam["focal_dist"], cam["aperture"], normalise=move is not None)
         ref, _ = o.render(ocam, W, H, D, 0, spp, 33)
         assert np.array_equal(culled, ref), move
         if move is None and cfg in ("C3", "C1"):
