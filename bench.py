@@ -84,7 +84,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check beside the number")
     ap.add_argument("--no-contracted", action="store_true", help="skip the contracted-build measurement")
     ap.add_argument("--no-interactive", action="store_true", help="skip the RenderFrame()-per-iteration measurement")
-    ap.add_argument("--rank-timeout", type=float, default=120.0,
+    ap.add_argument("--rank-timeout", type=float, default=150.0,
                     help="N > 1: bound in seconds of every wait on another rank (rendezvous, RCCL communicator, exchange, barriers)")
     ap.add_argument("--wall-limit", type=float, default=540.0, help="N > 1, self-launched: the parent ends the ranks after this many seconds")
     ap.add_argument("--rehearse-launch", action="store_true",
@@ -581,7 +581,7 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
         "frac_from_kernel_ms_note": "SURVEY 8(d4) flops of one step / (median in-loop launch duration x launches per step) / 157.3 TFLOP/s: recompute it from "
                                     "valu.flops_per_sample x width x height x spp_per_step and profiles/r04/rocprofv3_kernel_stats_<config>.csv",
         "accumulate_kernel_ms": round(float(np.mean(acc_ms)), 4),
-        "computed_from": "ms_per_step (timed region; consecutive launches overlap their tails - profiles/r03/overlap_trace_C2.json - so a step is shorter than an isolated launch)",
+        "computed_from": "ms_per_step (timed region; consecutive launches overlap their tails - profiles/r04/overlap_trace_C2.json - so a step is shorter than an isolated launch)",
         "valu": {"flops_per_sample": round(d4_flops, 1), "achieved_TFLOPs": round(valu_tflops, 2), "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 4),
                  "note": "SURVEY 8(d4) flops: 30 / box test, 50 / triangle test, 250 / shaded hit; the peak counts an FMA as 2 flops, which the "
                          "exact build (-ffp-contract=off) forgoes: 0.5 is its ceiling (value_contracted lifts that)"},
@@ -601,17 +601,17 @@ def measure(name: str, args, rank: int, world: int, local_rank: int, steps: int,
                                   "camera": round(stats["gen_lanes"] / max(1, stats["gen_wave_execs"]) / 64.0, 3)},
     })
     sq = None
-    for rdir in ("r03", "r02"):
+    for rdir in ("r04", "r03", "r02"):
         sq_file = os.path.join(ROOT, "profiles", rdir, f"pmc_sq_trace_kernel_{name}.json")
         if os.path.exists(sq_file) and world == 1:
             try:
                 sq = json.load(open(sq_file))
-                if rdir == "r03" and sq.get("kernel_source_sha256") != kernel_source_sha256():
+                if rdir != "r02" and sq.get("kernel_source_sha256") != kernel_source_sha256():
                     sq = None
                     continue
                 roofline["valu"]["pipe_busy_bounds_offline"] = [sq.get("valu_pipe_busy_low"), min(1.0, sq.get("valu_pipe_busy_high", 1.0))]
                 roofline["valu"]["lane_utilisation_offline"] = sq.get("lane_utilisation")
-                roofline["valu"]["offline_source"] = f"profiles/{rdir}/pmc_sq_trace_kernel_{name}.json" + ("" if rdir == "r03" else " (an earlier round's kernels)")
+                roofline["valu"]["offline_source"] = f"profiles/{rdir}/pmc_sq_trace_kernel_{name}.json" + ("" if rdir != "r02" else " (an earlier round's kernels)")
                 break
             except Exception:
                 pass

@@ -457,17 +457,17 @@ def test_dropin_header_compiles_and_links_natively(tmp_path):
 
 
 def test_committed_counter_files_belong_to_the_kernels_as_built():
-    """profiles/traffic_C*.json (what bench.py's roofline.traffic is read from) and profiles/r03/pmc_sq_*.json carry the sha256
+    """profiles/traffic_C*.json (what bench.py's roofline.traffic is read from) and profiles/r04/pmc_sq_*.json carry the sha256
     of the kernel sources they were collected for; bench.py ignores them once the sources change.  This keeps the committed
-    set honest: whoever edits csrc/ptk_kernels.hip or csrc/ptk_device.h re-runs tools/profile_r03.sh (or sees this fail)."""
+    set honest: whoever edits csrc/ptk_kernels.hip or csrc/ptk_device.h re-runs tools/profile_round.sh (or sees this fail)."""
     import glob
     import importlib.util
     import json
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     sha = bench.kernel_source_sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_C*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r03", "pmc_sq_trace_kernel_C*.json")) +
-                   glob.glob(os.path.join(ROOT, "profiles", "r03", "overlap_trace_C2.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_C*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r04", "pmc_sq_trace_kernel_C*.json")) +
+                   glob.glob(os.path.join(ROOT, "profiles", "r04", "overlap_trace_C2.json")))
     assert len(files) >= 8
     for f in files:
         assert json.load(open(f)).get("kernel_source_sha256") == sha, f + " was collected for other kernel sources"
