@@ -316,7 +316,19 @@ def interactive_probe(pt, ctx, W, H, frames=200):
         pt.RenderFrame()
     ctx.synchronize()
     out["ms_per_RenderFrame"] = round((time.perf_counter() - t0) / frames * 1e3, 4)
-    out["handoff"] = "8-bit resolve written by accumulate_kernel straight into the caller's page-locked buffer (ptk_bind_out_image); no copy command"
+    out["handoff"] = "8-bit resolve written by accumulate_kernel straight into the caller's page-locked buffer (ptk_host_alloc, ptk_bind_out_image); no copy command"
+    # ... and into ORDINARY memory, what the viewer's `new GLubyte[w*h*3]` is (main.cpp:3435): never registered with the runtime (round 4),
+    # the resolved frame is copied into it after every RenderFrame()
+    plain = np.zeros((H, W, 3), np.uint8)
+    pt.SetOutImage(plain)
+    for _ in range(10):
+        pt.RenderFrame()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        pt.RenderFrame()
+    out["with_pageable_handoff_ms"] = round((time.perf_counter() - t0) / frames * 1e3, 4)
+    out["pageable_frame_matches_device"] = bool(np.array_equal(plain, ctx.resolve_rgb8()))
+    pt.SetOutImage(None)
     # ... and with the frame staying on the GPU (ptk_bind_out_device: what ptk_bind_gl_buffer maps the viewer's pixel-unpack buffer
     # to - the OpenGL leg itself cannot run on a headless box)
     import torch
