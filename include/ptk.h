@@ -243,9 +243,15 @@ int ptk_probe_unpack(ptk_ctx* ctx, int world, const float* host_packed /* all ra
  * trees of depth <= 4, else 68, or 46 for trees of 131 072 nodes and more (0 = this automatic choice), camera rays 16);
  * "tri_threshold" = the
  * triangle arm of the BVH walk runs once the lanes holding a leaf reach this many eighths of the lanes
- * that can still walk (default 4; 0 = every iteration); "device_build" = 0/1 (default 1): build the BVH of scenes of >= 4096 triangles on the GPU;
+ * that can still walk (default 6; 0 = every iteration); "device_build" = 0/1 (default 1): build the BVH of scenes of >= 4096 triangles on the GPU;
  * "primary_cache" = 0/1, reuse the camera ray's closest
  * hit across samples when the camera is a pinhole and the scene has no opacity texture (default 1);
+ * "lens_cull" = 0/1 (default 1): cameras whose rays are NOT cached (thin lens, opacity textures) leave out the pixels none of whose
+ * lens rays can reach the scene's bounding box - exact: the image is the same bit for bit either way (tests / A-B only);
+ * "comm_timeout_s" = bound in seconds of every wait on another rank (ptk_comm_init, ptk_gather_wait, ptk_read_gathered; default 120);
+ * "register_out_image" = 0/1 (default 0): see ptk_bind_out_image;
+ * "pass_bytes" is an upper bound: a render never asks for more than half of the device memory that is free (hipMemGetInfo), and
+ * a pass whose sample buffer cannot be allocated is halved and tried again - more passes, the same image;
  * "pool" = paths per wave of the pooled BVH kernel (trace_pool_kernel: 64..256, a multiple of 64; default 0 = the one-path-per-lane
  * megakernel), "fetch_threshold" / "switch_threshold" = its scheduling lambdas in eighths (defaults 3 / 16);
  * "bvh_leaf_max" (1..8), "bvh_trav_cost" (SAH cost of a node visit in triangle tests), "bvh_verbose" = builder tuning, process-wide,
