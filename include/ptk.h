@@ -252,8 +252,6 @@ int ptk_probe_unpack(ptk_ctx* ctx, int world, const float* host_packed /* all ra
  * "register_out_image" = 0/1 (default 0): see ptk_bind_out_image;
  * "pass_bytes" is an upper bound: a render never asks for more than half of the device memory that is free (hipMemGetInfo), and
  * a pass whose sample buffer cannot be allocated is halved and tried again - more passes, the same image;
- * "pool" = paths per wave of the pooled BVH kernel (trace_pool_kernel: 64..256, a multiple of 64; default 0 = the one-path-per-lane
- * megakernel), "fetch_threshold" / "switch_threshold" = its scheduling lambdas in eighths (defaults 3 / 16);
  * "bvh_leaf_max" (1..8), "bvh_trav_cost" (SAH cost of a node visit in triangle tests), "bvh_verbose" = builder tuning, process-wide,
  * effective at the next ptk_upload_scene (0 = the builders' own choices: 4 / 1.0 / quiet): they shape the tree, and closest hits do
  * not depend on the tree.

@@ -108,12 +108,6 @@ struct ptk_ctx {
     float4* d_samples2[2] = { nullptr, nullptr };
     size_t samples_bytes2[2] = { 0, 0 };
     unsigned* d_queues2[2] = { nullptr, nullptr };
-    // trace_pool_kernel's path pools, one per trace stream (index 2: the non-overlapped path): blocks x slots x 128 B
-    float4* d_pool[3] = { nullptr, nullptr, nullptr };
-    size_t pool_bytes[3] = { 0, 0, 0 };
-    int opt_pool = 0;                            // paths per wave of the pooled BVH kernel (multiple of 64, <= 256); 0: trace_kernel<BVH>
-    int opt_switch_thr = 16;                     // eighths of a wave-iteration: how long lanes may wait, all jobs dealt, before the trace phase ends
-    int opt_fetch_thr = 3;                       // eighths: a free lane takes its next job once its waiting outweighs fetch_thr/8 x walking lanes
     hipStream_t trace_stream[2] = { nullptr, nullptr };
     hipEvent_t ev_trace_done[2] = { nullptr, nullptr }, ev_acc_done[2] = { nullptr, nullptr }, ev_inputs = nullptr;
     bool acc_pending[2] = { false, false }, inputs_recorded = false;
@@ -501,25 +495,6 @@ int run_passes(ptk_ctx* c, uint32_t first, uint32_t spp, uint64_t seed, bool sta
             if (c->acc_pending[b]) HIPCHK(c, hipStreamWaitEvent(tstream, c->ev_acc_done[b], 0));   // buffer b was last read by pass k-2's accumulate
         }
         else p.samples = c->d_samples;
-        p.pool = nullptr; p.pool_slots = 0; p.pool_blocks = 0; p.fetch_thr = c->opt_fetch_thr; p.switch_thr = c->opt_switch_thr;
-        if (c->opt_pool >= 64 && p.flat_count == 0)
-        {
-            // the pooled kernel runs persistent launches only; its pool is sized for the most workgroups such a launch starts
-            const int gens = c->opt_generations > 0 ? c->opt_generations : (c->world > 1 ? 2 : 1);
-            const int pool_blocks = c->resident_waves * std::max(1, gens);
-            const int slots = std::min(256, c->opt_pool / 64 * 64);
-            const size_t pneed = (size_t)pool_blocks * (size_t)(slots * 8 + 128) * sizeof(float4);      // PTK_POOL_F4: slots + 64 suspend records
-            const int pi_ = overlap ? b : 2;
-            if (pneed > c->pool_bytes[pi_])
-            {
-                HIPCHK(c, hipStreamSynchronize(tstream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                dfree(c->d_pool[pi_]); c->pool_bytes[pi_] = 0;
-                HIPCHK(c, hipMalloc(&c->d_pool[pi_], pneed));
-                c->pool_bytes[pi_] = pneed;
-            }
-            p.pool = c->d_pool[pi_]; p.pool_slots = slots; p.pool_blocks = (int)(c->pool_bytes[pi_] / ((size_t)(slots * 8 + 128) * sizeof(float4)));
-        }
         p.first_sample = first + done; p.spp = n;
         p.chunk = chunk; p.num_chunks = num_chunks;
         p.resolve_samples = (float)(first + done + n);
@@ -628,7 +603,6 @@ void ptk_destroy(ptk_ctx* c)
         if (c->ev_acc_done[b]) (void)hipEventDestroy(c->ev_acc_done[b]);
         dfree(c->d_samples2[b]); dfree(c->d_queues2[b]);
     }
-    for (int b = 0; b < 3; b++) dfree(c->d_pool[b]);
     if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
     if (c->xstream) { (void)hipStreamSynchronize(c->xstream); }
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
@@ -1662,18 +1636,6 @@ int ptk_set_option(ptk_ctx* c, const char* name, double value)
         // builder tuning (process-wide, takes effect at the next ptk_upload_scene; 0 = the builders' own choices)
         if (!(value >= 0 && value <= 64)) return fail(c, PTK_ERR_BAD_ARG, "builder tuning value must be in [0, 64]");
         if (name[4] == 'l') g_bvh_tuning.leaf_max = (int)value; else if (name[4] == 't') g_bvh_tuning.trav_cost = (float)value; else g_bvh_tuning.verbose = (int)value;
-        return PTK_OK;
-    }
-    if (!std::strcmp(name, "pool"))
-    {
-        if (!(value >= 0 && value <= 256)) return fail(c, PTK_ERR_BAD_ARG, "pool (paths per wave of the pooled BVH kernel) must be in [0, 256]; 0 = trace_kernel<BVH>");
-        c->opt_pool = (int)value;
-        return PTK_OK;
-    }
-    if (!std::strcmp(name, "fetch_threshold") || !std::strcmp(name, "switch_threshold"))
-    {
-        if (!(value >= 0 && value <= 65536)) return fail(c, PTK_ERR_BAD_ARG, "threshold (eighths) must be in [0, 65536]");
-        (name[0] == 'f' ? c->opt_fetch_thr : c->opt_switch_thr) = (int)value;
         return PTK_OK;
     }
     if (!std::strcmp(name, "contract"))

@@ -54,10 +54,6 @@ enum { QG_NUM_CHUNKS = 0, QG_WORLD, QG_RANK, QG_TILES_X, QG_CHUNK, QG_SPP, QG_SL
 
 struct RenderParams {
     float4* samples;
-    float4* pool;               // trace_pool_kernel: pool_blocks x pool_slots x 8 float4 of path records (null: trace_kernel)
-    int pool_slots, pool_blocks;// paths per wave (multiple of 64, <= PTK_POOL_MAX); workgroups the pool was allocated for
-    int fetch_thr;              // a lane takes its next job when the lane-iterations spent waiting reach fetch_thr/8 x walking lanes
-    int switch_thr;             // jobs all dealt: the trace phase ends when the lane-iterations spent waiting reach switch_thr/8 x 64
     int chunk, num_chunks;      // samples per work item, work items per 8x8 tile
     int num_items;              // owned tiles * 4 * num_chunks
     int max_batch;              // most slots a wave pops from a queue at once

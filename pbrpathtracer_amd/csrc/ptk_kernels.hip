@@ -1402,398 +1402,6 @@ __global__ __launch_bounds__(PTK_TRACE_BLOCK, (FLAT ? PTK_TRACE_WAVES : PTK_TRAC
     }
 }
 
-// ---- pooled BVH kernel --------------------------------------------------------------------------------------------------
-// The same megakernel - persistent one-wave workgroups, one path per lane, the same items / units / queues, walk_step and
-// shade_interaction - with MORE PATHS THAN LANES: every wave owns a pool of P.pool_slots paths (a multiple of 64) whose
-// state lives in a private block of device memory (128 B per path: a 64-byte job record the walk reads and a 64-byte
-// state record only shading touches), and alternates two phases over it:
-//   SHADE  the paths whose ray has been traced (and the units dealt into free slots) are shaded 64 at a time, compacted
-//          through a list in LDS: the shade block always runs with a full wave, instead of with the quarter to half of a
-//          wave that happen to wait for it while the other lanes walk (lane utilisation of the shade block 0.47-0.54 in
-//          trace_kernel<BVH>, profiles/r02);
-//   TRACE  the jobs (shadow ray + bounce ray of one interaction, as in trace_kernel) are dealt to the lanes dynamically:
-//          a lane whose job is finished stores the hit and takes the next job of the list, its record requested one walk
-//          iteration ahead.  The phase ends as soon as lanes run out of jobs - NOT when the last walk has finished (walk
-//          lengths are heavy-tailed: draining the wave costs more than the pool gains): the walks still in flight are
-//          SUSPENDED (ten words per lane; the lane's LDS stack column stays as it is) and resumed in the same lane when
-//          the next trace phase begins, next to the fresh jobs.  So no lane parks for shading while others walk, and none
-//          idles behind a long walk.
-// Nothing but a handful of counters is live in registers across the phases, so the walk loop is compiled without the
-// shading state and the shade block without the walk's.  Paths never leave their wave: no atomics, no barriers between
-// waves, no queue contention; the arithmetic per path is the very same sequence (same RNG stream, same order of additions
-// into L), so images are bit-identical with trace_kernel's and the oracle's.  Used for launches big enough to be
-// persistent (launch_trace decides).
-//
-// Pool record of slot s (float4 units, base = pool + s * 8):
-//   J0 = (ray origin p, bits occl_tri)           J1 = (first direction d1, bits rng.key)
-//   J2 = (second direction d2, bits ray number)  J3 = (bits tri, t, u, v)
-//      job: walk (p, d1) - a shadow ray towards light triangle occl_tri when occl_tri >= 0, J3 then holding the light
-//      triangle's own hit - then, after a shadow ray, the bounce ray (p, d2).  Result: J3 = closest hit of the bounce ray
-//      (the LAST ray), the sign bit of t set when the shadow ray found its light (t itself is positive or +inf).
-//   S0 = (L, rng.state)  S1 = (T, rng.inc)  S2 = (Tdi, bits depth)  S3 = (bits pix, bits out_idx, bits iter | inside << 31,
-//      bits fresh: 0x80000000 | sample index when the slot holds a unit that has not been started yet)
-// Suspend record of lane l (behind the slots: pool + pool_slots * 8 + l * 2):
-//   X0 = (bits node, bits flags, bits tri_next, bits slot)   X1 = best (bits tri, t, u, v)
-//      flags: bits 0-7 stack entries, 8-11 tri_left, 16 lit, 17 the bounce ray of the job is being walked, 31 in use
-#ifndef PTK_POOL_MAX
-#define PTK_POOL_MAX 256            // (slot numbers travel through LDS as bytes; with the 8 KiB stack 16 waves still fit a CU's LDS)
-#endif
-#define PTK_POOL_F4(slots) ((slots) * 8 + 128)      // float4 per workgroup: the slots + 64 suspend records
-enum : int { J_NEED = 0, J_LOAD = 1, J_WALK = 2 };
-
-template <bool STATS>
-__global__ __launch_bounds__(PTK_TRACE_BLOCK, PTK_TRACE_WAVES_BVH) void trace_pool_kernel(const RenderParams* __restrict__ Pp)
-{
-    typedef const __attribute__((address_space(4))) RenderParams ConstParams;      // (see trace_kernel)
-    ConstParams& P = *(ConstParams*)(uintptr_t)Pp;
-    __shared__ int lds_stack[(PTK_MAX_BVH_DEPTH + PTK_PUSH_BRANCHLESS) * PTK_TRACE_BLOCK];
-    __shared__ unsigned char lds_jobs[PTK_POOL_MAX], lds_done[PTK_POOL_MAX], lds_free[PTK_POOL_MAX];
-    static_assert(PTK_POOL_MAX <= 256, "slot numbers are bytes");
-    __shared__ unsigned char lds_pixel_of_rank[64];
-    __shared__ uint32_t lds_item[IT_WORDS];
-    if (P.exit_flag && __hip_atomic_load(P.exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.exit_gen) return;     // an Exit() named this render or a later one
-    static_assert(PTK_TRACE_BLOCK == 64, "one wave per workgroup");
-    const int lane = threadIdx.x;
-    int* const stack = lds_stack + lane;
-    const int pool_slots = P.pool_slots;
-    float4* const pool = P.pool + (size_t)blockIdx.x * (size_t)PTK_POOL_F4(pool_slots);
-    float4* const susp = pool + pool_slots * 8 + lane * 2;
-    if (lane == 0)
-    {
-        lds_item[IT_STEAL] = 0u; lds_item[IT_LO] = 0u; lds_item[IT_HI] = 0u;
-        lds_item[IT_G] = (uint32_t)blockIdx.x & 7u;
-        lds_item[IT_REMAIN] = 0xffffffffu;
-        lds_item[IT_TAKEN] = 0u;
-    }
-    for (int i = lane; i < pool_slots; i += 64) lds_free[i] = (unsigned char)i;
-    __syncthreads();
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t total_units = 0, next_unit = 0;    // wave-uniform: the item being dealt
-    bool units_left = true;
-    int n_jobs = 0, n_done = 0, n_free = pool_slots;    // wave-uniform list lengths
-    unsigned long long m_susp = 0ull;           // lanes whose walk is suspended (its state is in `susp`)
-
-    const v3 camPos0 = V(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
-    const v3 camRight = V(P.cam_right[0], P.cam_right[1], P.cam_right[2]);
-    const v3 camUp = V(P.cam_up[0], P.cam_up[1], P.cam_up[2]);
-    Counters cnt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-
-    for (;;)
-    {
-        // ---- REFILL: units are dealt into the free slots; such a slot only holds (pixel, sample, output slot) until the
-        // shade phase below starts its path
-        while (n_free > 0 && units_left)
-        {
-            if (next_unit >= total_units)
-            {
-                next_unit = 0;
-                // (readfirstlane: the value comes out of LDS, which the compiler takes for lane-dependent - and with it every
-                // count derived from it, turning the phase loops' wave-uniform exits into exec-masked ones)
-                total_units = (uint32_t)__builtin_amdgcn_readfirstlane((int)acquire_work_item(P, lds_item, lds_pixel_of_rank, lane));
-                if (total_units == 0) { units_left = false; break; }
-            }
-            const int take = min(min(64, n_free), (int)(total_units - next_unit));
-            if (lane < take)
-            {
-                const uint32_t n_live = lds_item[IT_NLIVE];
-                const uint32_t u = next_unit + (uint32_t)lane;
-                const uint32_t s_in_chunk = n_live == 1u ? u : __umulhi(u, lds_item[IT_NLIVE_MAGIC]);
-                const uint32_t q = lds_pixel_of_rank[u - s_in_chunk * n_live];
-                const uint32_t pix = (lds_item[IT_Y0] + (q >> 3)) * (uint32_t)P.width + lds_item[IT_X0] + (q & 7u);
-                const uint32_t sample_abs = lds_item[IT_SBEGIN] + s_in_chunk;
-                const uint32_t out_idx = lds_item[IT_OUTBASE] + s_in_chunk * 64u + q;
-                const int slot = lds_free[n_free - 1 - lane];
-                pool[slot * 8 + 7] = make_float4(__uint_as_float(pix), __uint_as_float(out_idx), 0.0f, __uint_as_float(0x80000000u | sample_abs));
-                lds_done[n_done + lane] = (unsigned char)slot;
-            }
-            n_free -= take; n_done += take; next_unit += (uint32_t)take;
-        }
-        if (n_done == 0 && n_jobs == 0 && m_susp == 0ull) break;          // no unit left to deal and no path alive
-        __syncthreads();
-
-        // ---- SHADE phase: everything on the done list -----------------------------------------------------------------
-        for (int c = 0; c < n_done; c += 64)
-        {
-            const int k = c + lane;
-            const bool act = k < n_done;
-            const int slot = act ? (int)lds_done[k] : 0;
-            float4* const rec = pool + slot * 8;
-            bool has_job = false, finished = false;
-            if (STATS) { const uint32_t na = (uint32_t)__popcll(__ballot(act)); if (lane == 0) { cnt.shade_execs++; cnt.shade_lanes += na; } }
-            if (act)
-            {
-                const float4 S3 = rec[7];
-                const uint32_t pix = __float_as_uint(S3.x), out_idx = __float_as_uint(S3.y), fresh = __float_as_uint(S3.w);
-                Walk W, WS;
-                Rng rng;
-                v3 L, T, Tdi = V(0.0f, 0.0f, 0.0f), nextDir = V(0.0f, 0.0f, 1.0f);
-                int depth, iter;
-                bool inside, need_shade = false;
-                uint32_t ray;
-                W.occl_tri = -1; W.node = NODE_EXIT; W.top = stack; W.tri_next = 0; W.tri_left = 0;
-                if (fresh != 0u)
-                {
-                    // a unit dealt since the last shade phase: its path starts here
-                    const uint2 pr = P.pixel_rng[pix];
-                    rng.inc = pr.y;
-                    rng.state = hash32(P.first_sample + (fresh & 0x7fffffffu) + pr.x);
-                    rng.key = rng.state;
-                    L = V(0.0f, 0.0f, 0.0f); T = V(1.0f, 1.0f, 1.0f);
-                    depth = 0; iter = 0; inside = false;
-                    if (STATS) cnt.started++;
-                    if (P.primary_hit)
-                    {
-                        // pinhole camera, no stochastic opacity: the camera ray's hit is cached per pixel (see trace_kernel);
-                        // the two SampleCircle draws only advance the stream
-                        rng.state = rng.state * (747796405u * 747796405u) + rng.inc * (747796405u + 1u);
-                        const float4 ch = P.primary_hit[pix], r = P.primary_rd[pix];
-                        W.ro = camPos0; W.rd = V(r.x, r.y, r.z);
-                        W.best.tri = __float_as_int(ch.x); W.best.t = ch.y; W.best.u = ch.z; W.best.v = ch.w;
-                        ray = 1;
-                        need_shade = true;      // (pixels whose camera ray misses are never dealt)
-                    }
-                    else
-                    {
-                        // ---- camera ray with thin-lens DOF, pathtracer.cpp:785-791 + SampleCircle :734-739 ----
-                        const float4 d0 = P.primary[pix];
-                        const v3 dir0 = V(d0.x, d0.y, d0.z);
-                        v3 focalPoint = add(camPos0, muls(dir0, P.focal_dist));
-                        float r1 = rng.next(), r2 = rng.next();          // always two draws, even with a pinhole
-                        v3 ro = camPos0;
-                        if (P.aperture != 0.0f)
-                        {
-                            float angle = (float)((double)r1 * 2. * PTK_PI_D);
-                            float radius = sqrt_ieee(r2);
-                            float sn, cs;
-                            sincos_2pi(angle, sn, cs);
-                            float offx = (cs * radius) * P.aperture, offy = (sn * radius) * P.aperture;
-                            ro = add(camPos0, add(muls(camRight, offx), muls(camUp, offy)));
-                        }
-                        v3 rd = normalize(sub(focalPoint, ro));
-                        W.ro = ro; W.rd = rd;
-                        W.best.tri = PTK_NOHIT; W.best.t = __builtin_inff(); W.best.u = 0.0f; W.best.v = 0.0f;
-                        ray = 0;
-                        has_job = true;
-                    }
-                }
-                else
-                {
-                    const float4 J0 = rec[0], J1 = rec[1], J2 = rec[2], J3 = rec[3], S0 = rec[4], S1 = rec[5], S2 = rec[6];
-                    L = V(S0.x, S0.y, S0.z); T = V(S1.x, S1.y, S1.z); Tdi = V(S2.x, S2.y, S2.z);
-                    rng.state = __float_as_uint(S0.w); rng.inc = __float_as_uint(S1.w); rng.key = __float_as_uint(J1.w);
-                    depth = __float_as_int(S2.w);
-                    iter = (int)(__float_as_uint(S3.z) & 0x7fffffffu); inside = (__float_as_uint(S3.z) >> 31) != 0u;
-                    const bool had_shadow = __float_as_int(J0.w) >= 0;
-                    // pathtracer.cpp:522-526: the shadow ray found its light - DirectIllumimation's value joins L before
-                    // anything the bounce ray leads to (the order trace_kernel adds in)
-                    if (had_shadow && __float_as_int(J3.y) < 0) L = add(L, Tdi);
-                    ray = __float_as_uint(J2.w) + (had_shadow ? 2u : 1u);
-                    const int tri = __float_as_int(J3.x);
-                    if (tri == PTK_NOHIT) finished = true;              // :550 miss -> black
-                    else
-                    {
-                        W.ro = V(J0.x, J0.y, J0.z);
-                        W.rd = had_shadow ? V(J2.x, J2.y, J2.z) : V(J1.x, J1.y, J1.z);
-                        W.best.tri = tri; W.best.t = fabsf(J3.y); W.best.u = J3.z; W.best.v = J3.w;
-                        need_shade = true;
-                    }
-                }
-                if (need_shade)
-                {
-                    const bool ended = shade_interaction<STATS, false>(P, W, WS, stack, rng, L, T, Tdi, nextDir, depth, iter, inside, ray, cnt);
-                    finished = ended; has_job = !ended;
-                }
-                if (finished) P.samples[out_idx] = make_float4(L.x, L.y, L.z, 0.0f);
-                if (has_job)
-                {
-                    rec[0] = make_float4(W.ro.x, W.ro.y, W.ro.z, __int_as_float(W.occl_tri));
-                    rec[1] = make_float4(W.rd.x, W.rd.y, W.rd.z, __uint_as_float(rng.key));
-                    rec[2] = make_float4(nextDir.x, nextDir.y, nextDir.z, __uint_as_float(ray));
-                    rec[3] = make_float4(__int_as_float(W.best.tri), W.best.t, W.best.u, W.best.v);
-                    rec[4] = make_float4(L.x, L.y, L.z, __uint_as_float(rng.state));
-                    rec[5] = make_float4(T.x, T.y, T.z, __uint_as_float(rng.inc));
-                    rec[6] = make_float4(Tdi.x, Tdi.y, Tdi.z, __int_as_float(depth));
-                    rec[7] = make_float4(S3.x, S3.y, __uint_as_float((uint32_t)iter | (inside ? 0x80000000u : 0u)), 0.0f);
-                }
-            }
-            // a path either has a job for the next trace phase or returns its slot (the job list is empty when shading
-            // begins: the trace phase only ends once every job has been dealt)
-            const unsigned long long m_job = __ballot(has_job), m_fin = __ballot(finished);
-            if (has_job) lds_jobs[n_jobs + __popcll(m_job & lt_mask)] = (unsigned char)slot;
-            if (finished) lds_free[n_free + __popcll(m_fin & lt_mask)] = (unsigned char)slot;
-            n_jobs += __popcll(m_job); n_free += __popcll(m_fin);
-        }
-        n_done = 0;
-        __syncthreads();                        // the job records are read by other lanes than wrote them
-        if (n_jobs == 0 && m_susp == 0ull) continue;
-
-        // ---- TRACE phase: the suspended walks resume, the list's jobs are dealt to whichever lane is free -------------------
-        {
-            Walk W;
-            W.begin(camPos0, V(0.0f, 0.0f, 1.0f), 0, stack, 0.0f);
-            W.occl_tri = -1;
-            Rng rng; rng.inc = 1u; rng.state = 0u; rng.key = 0u;      // (the walk only needs the key: stochastic opacity)
-            v3 nextDir = V(0.0f, 0.0f, 1.0f);
-            float4 tj0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), tj1 = tj0, tj2 = tj0, tj3 = tj0;   // the job record in flight
-            uint32_t ray = 0;
-            int jst = J_NEED, slot_cur = 0;
-            bool lit = false;
-            if ((m_susp >> lane) & 1ull)
-            {
-                const float4 X0 = susp[0], X1 = susp[1];
-                const uint32_t fl = __float_as_uint(X0.y);
-                slot_cur = __float_as_int(X0.w);
-                const float4* rec = pool + slot_cur * 8;
-                const float4 J0 = rec[0], J1 = rec[1], J2 = rec[2];
-                const bool in_bounce = (fl >> 17) & 1u, had_shadow = __float_as_int(J0.w) >= 0;
-                // (the second ray of a job with a shadow ray goes along d2; any other ray along d1)
-                W.begin(V(J0.x, J0.y, J0.z), (in_bounce && had_shadow) ? V(J2.x, J2.y, J2.z) : V(J1.x, J1.y, J1.z), P.num_nodes, stack, P.scene_bound);
-                W.occl_tri = in_bounce ? -1 : __float_as_int(J0.w);
-                rng.key = __float_as_uint(J1.w);
-                nextDir = V(J2.x, J2.y, J2.z);
-                ray = __float_as_uint(J2.w) + ((in_bounce && had_shadow) ? 1u : 0u);
-                W.node = __float_as_int(X0.x);
-                W.top = stack + (int)(fl & 255u) * PTK_TRACE_BLOCK;
-                W.tri_left = (int)((fl >> 8) & 15u);
-                W.tri_next = __float_as_int(X0.z);
-                W.best.tri = __float_as_int(X1.x); W.best.t = X1.y; W.best.u = X1.z; W.best.v = X1.w;
-                lit = (fl >> 16) & 1u;
-                jst = J_WALK;
-            }
-            const WalkParams WP = walk_params(P);          // the loop's share of the parameters, in SGPRs (see trace_kernel)
-            int next = 0, dg = 0;               // wave-uniform: next job to deal; lane-iterations spent waiting for a job
-            bool stop = false;                  // wave-uniform; ONE loop exit and no `continue`: the loop's latch stays a scalar branch
-            do
-            {
-                // a job whose record was requested in the previous iteration starts walking: its loads were in flight
-                // behind that iteration's node and triangle records
-                bool fin = false;               // this lane finished a job in this iteration
-                if (jst == J_LOAD)
-                {
-                    W.begin(V(tj0.x, tj0.y, tj0.z), V(tj1.x, tj1.y, tj1.z), P.num_nodes, stack, P.scene_bound);
-                    W.occl_tri = __float_as_int(tj0.w);
-                    rng.key = __float_as_uint(tj1.w);
-                    nextDir = V(tj2.x, tj2.y, tj2.z);
-                    ray = __float_as_uint(tj2.w);
-                    if (W.occl_tri >= 0) { W.best.tri = __float_as_int(tj3.x); W.best.t = tj3.y; W.best.u = tj3.z; W.best.v = tj3.w; }
-                    lit = false;
-                    jst = J_WALK;
-                    if (W.done())                          // (a scene without a single node: every ray misses)
-                    {
-                        pool[slot_cur * 8 + 3] = make_float4(__int_as_float(PTK_NOHIT), __builtin_inff(), 0.0f, 0.0f);
-                        jst = J_NEED; fin = true;
-                    }
-                }
-                const unsigned long long m_tq = __ballot(W.tri_left > 0), m_nr = __ballot(W.node >= 0);
-                const int n_walk = __popcll(m_tq | m_nr);
-                const unsigned long long m_need = __ballot(jst == J_NEED);
-                const int n_need = __popcll(m_need);
-                // (wave-uniform by construction; said explicitly so that the loop's branches stay scalar)
-                next = __builtin_amdgcn_readfirstlane(next); dg = __builtin_amdgcn_readfirstlane(dg);
-                n_done = __builtin_amdgcn_readfirstlane(n_done);
-                if (n_need > 0)
-                {
-                    if (next < n_jobs)
-                    {
-                        if (n_walk == 0 || dg * 8 >= P.fetch_thr * n_walk)
-                        {
-                            const int k = next + __popcll(m_need & lt_mask);
-                            if (STATS) { const uint32_t nf = (uint32_t)min(n_need, n_jobs - next); if (lane == 0) { cnt.gen_execs++; cnt.gen_lanes += nf; } }
-                            if (jst == J_NEED && k < n_jobs)
-                            {
-                                slot_cur = (int)lds_jobs[k];
-                                const float4* rec = pool + slot_cur * 8;
-                                tj0 = rec[0]; tj1 = rec[1]; tj2 = rec[2]; tj3 = rec[3];
-                                jst = J_LOAD;
-                            }
-                            next = min(n_jobs, next + n_need);
-                            dg = 0;
-                        }
-                    }
-                    else if ((n_walk == 0 || dg * 8 >= P.switch_thr * 64) && __ballot(jst == J_LOAD) == 0ull)
-                    {
-                        // every job has been dealt and lanes are waiting: the phase ends here if there is anything to shade
-                        // or to deal, with the walks in flight suspended - and in any case when nobody walks
-                        stop = n_walk == 0 || n_done + __popcll(__ballot(fin)) > 0 || (units_left && n_free > 0);
-                    }
-                }
-                if (!stop && n_walk > 0)
-                {
-                    dg += n_need;
-                    if (STATS && lane == 0) { cnt.walk_iters++; cnt.walk_lanes += (uint32_t)n_walk; }
-                    // the triangle arm is voted as in trace_kernel
-                    const int n_tq = __popcll(m_tq), n_nr = __popcll(m_nr);
-                    const bool run_tri_arm = (n_tq > 0) & ((n_nr == 0) | (n_tq * 8 >= WP.tri_thr * n_nr));
-                    if (STATS && lane == 0 && run_tri_arm) { cnt.tri_execs++; cnt.tri_lanes += (uint32_t)n_tq; }
-                    if (jst == J_WALK)
-                    {
-                        walk_step<STATS, PTK_TRACE_BLOCK, false, 1>(WP, W, rng, ray, stack, cnt, run_tri_arm);      // (one triangle per execution: the pooled kernel has no registers to spare)
-                        if (W.done())
-                        {
-                            if (STATS) { cnt.rays++; cnt.max_nodes = max(cnt.max_nodes, cnt.cur_nodes); cnt.cur_nodes = 0; }
-                            ray++;
-                            const bool hit_ = W.best.tri != PTK_NOHIT;
-                            if (W.occl_tri >= 0)
-                            {
-                                // pathtracer.cpp:522-526: lit unless something else is closest; the bounce ray follows at once
-                                if (STATS) cnt.shadow++;
-                                lit = !(hit_ && W.best.tri != W.occl_tri);
-                                W.occl_tri = -1;
-                                W.begin(W.ro, nextDir, P.num_nodes, stack, P.scene_bound);
-                            }
-                            else
-                            {
-                                pool[slot_cur * 8 + 3] = make_float4(__int_as_float(W.best.tri), lit ? -W.best.t : W.best.t, W.best.u, W.best.v);
-                                jst = J_NEED; fin = true;
-                            }
-                        }
-                    }
-                }
-                // finished jobs go onto the done list for the next shade phase
-                const unsigned long long m_fin = __ballot(fin);
-                if (fin) lds_done[n_done + __popcll(m_fin & lt_mask)] = (unsigned char)slot_cur;
-                n_done += __popcll(m_fin);
-            } while (!stop);
-            // suspend the walks in flight: ten words per lane; the LDS stack column stays as it is (nothing in the shade
-            // phase touches the stack), and the walk resumes in this very lane
-            const bool walking = jst == J_WALK;
-            m_susp = __ballot(walking);
-            if (walking)
-            {
-                const bool in_bounce = W.occl_tri < 0;
-                const uint32_t fl = (uint32_t)((W.top - stack) / PTK_TRACE_BLOCK) | ((uint32_t)W.tri_left << 8) | (lit ? 1u << 16 : 0u) |
-                                    (in_bounce ? 1u << 17 : 0u) | 0x80000000u;
-                susp[0] = make_float4(__int_as_float(W.node), __uint_as_float(fl), __int_as_float(W.tri_next), __int_as_float(slot_cur));
-                susp[1] = make_float4(__int_as_float(W.best.tri), W.best.t, W.best.u, W.best.v);
-            }
-            n_jobs = 0;
-        }
-        __syncthreads();                        // the results are read by other lanes than wrote them
-    }
-    if (STATS)
-    {
-        atomicAdd(&P.stats[0], (unsigned long long)cnt.started);
-        atomicAdd(&P.stats[1], (unsigned long long)cnt.rays);
-        atomicAdd(&P.stats[2], (unsigned long long)cnt.shadow);
-        atomicAdd(&P.stats[3], (unsigned long long)cnt.nodes);
-        atomicAdd(&P.stats[4], (unsigned long long)cnt.tris);
-        atomicAdd(&P.stats[5], (unsigned long long)cnt.shaded);
-        atomicAdd(&P.stats[6], (unsigned long long)cnt.tex);
-        atomicMax(&P.stats[15], (unsigned long long)cnt.max_nodes);
-        if (lane == 0)
-        {
-            atomicAdd(&P.stats[7], (unsigned long long)cnt.walk_iters);
-            atomicAdd(&P.stats[8], (unsigned long long)cnt.walk_lanes);
-            atomicAdd(&P.stats[9], (unsigned long long)cnt.shade_execs);
-            atomicAdd(&P.stats[10], (unsigned long long)cnt.shade_lanes);
-            atomicAdd(&P.stats[11], (unsigned long long)cnt.gen_execs);
-            atomicAdd(&P.stats[12], (unsigned long long)cnt.gen_lanes);
-            atomicAdd(&P.stats[13], (unsigned long long)cnt.tri_execs);
-            atomicAdd(&P.stats[14], (unsigned long long)cnt.tri_lanes);
-        }
-    }
-}
-
 #if !PTK_CONTRACT      // ---- everything but the trace kernels exists once, in the exact build
 // Streaming fold of the sample buffer into the float accumulator, strictly in sample order
 // (`mTotalImg[px] += color` once per RenderFrame(), pathtracer.cpp:798-800), plus the 8-bit resolve
@@ -2150,16 +1758,12 @@ void launch_trace(const RenderParams& p0, int num_subtiles, int resident_waves, 
     hipLaunchKernelGGL(queue_init_kernel, dim3(1), dim3(64), 0, stream, p.queues, geo, p.live_count, p);
     const RenderParams* dp = queue_block_params(p.queues);
     const bool flat = p.flat_count > 0;
-    // the pooled kernel (more paths than lanes) needs persistent waves: one private pool block per workgroup
-    const bool pooled = !flat && p.persistent && p.pool != nullptr && p.pool_slots >= 64 && blocks <= p.pool_blocks;
 #if !PTK_CONTRACT
     if (stats && flat) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, dp);
-    else if (stats && pooled) hipLaunchKernelGGL((trace_pool_kernel<true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, dp);
     else if (stats) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, dp);
     else
 #endif
     if (flat) hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, dp);
-    else if (pooled) hipLaunchKernelGGL((trace_pool_kernel<false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, dp);
     else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(PTK_TRACE_BLOCK), 0, stream, dp);
 }
 

@@ -1,6 +1,6 @@
 """GPU box, one-off: random sequences of host-API calls on the drop-in PathTracer (camera, projection, lens, resolution, trace
 depth, seed, material edits after BuildBVH, another scene file into the same tracer, tile splits, Exit() with nothing in flight,
-the pooled kernel switched on and off, textures set on any slot after the build, BuildBVH again, further objects loaded into the scene, hand-off buffers of every kind coming and going, sample batching, a second tracer on the same GPU) - after every stage the
+persistent waves forced on and off, textures set on any slot after the build, BuildBVH again, further objects loaded into the scene, hand-off buffers of every kind coming and going, sample batching, a second tracer on the same GPU) - after every stage the
 accumulator must be the oracle's for the state the calls left behind.  python tools/soak_api.py [first_seed] [count]"""
 import os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -94,8 +94,8 @@ for k in range(count):
             pt.SetMaterial(k, 0, mm)
             pt.BuildBVH()
         else:
-            c = pt.context(); pooled = bool(rng.integers(0, 2))
-            c.set_option("persistent", 1 if pooled else -1); c.set_option("pool", int(rng.choice([64, 128, 256])) if pooled else 0)
+            c = pt.context(); forced = bool(rng.integers(0, 2))
+            c.set_option("persistent", 1 if forced else -1)
         if isinstance(out_img, str):
             Wc, Hc = st["W"], st["H"]
             if out_img.endswith("3"): out_img = torch.full((Hc, Wc, 3), 9, dtype=torch.uint8, device="cuda:0"); torch.cuda.synchronize()

@@ -77,7 +77,7 @@ for k in range(count):
         if not ok:
             bad += 1
             print(f"MISMATCH seed {seed} n {n} variant {variant} device_build {dev}", flush=True)
-        # SOAK_OPTS="persistent=1,pool=256;persistent=1,pool=64,switch_threshold=0": further option sets, each on the same scene
+        # SOAK_OPTS="persistent=1;flat=0,chunk=3": further option sets, each on the same scene
         for opts in [x for x in os.environ.get("SOAK_OPTS", "").split(";") if x]:
             kv = [p.split("=") for p in opts.split(",")]
             for k_, v_ in kv: ctx.set_option(k_, float(v_))
@@ -85,7 +85,7 @@ for k in range(count):
             if not (np.array_equal(ref, ctx.read_accum(), equal_nan=True) and np.array_equal(ref8, ctx.resolve_rgb8())):
                 bad += 1
                 print(f"MISMATCH seed {seed} n {n} variant {variant} device_build {dev} opts {opts}", flush=True)
-            for k_, v_ in kv: ctx.set_option(k_, {"persistent": -1, "pool": 0, "switch_threshold": 16, "fetch_threshold": 3, "flat": 1, "chunk": 0}.get(k_, 0))
+            for k_, v_ in kv: ctx.set_option(k_, {"persistent": -1, "flat": 1, "chunk": 0}.get(k_, 0))
     print(f"seed {seed} variant {variant}: {n} triangles {W}x{H} depth {D} ok, NaN pixels {int(np.isnan(ref).any(axis=2).sum())}, lit {(ref != 0).any(axis=2).mean():.2f}  [{time.time() - t0:.0f} s]", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
