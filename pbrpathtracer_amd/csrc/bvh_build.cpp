@@ -371,156 +371,4 @@ bool build_bvh(const float* verts, int32_t n, int max_depth, int leaf_max, Built
     return out.stack_need <= max_depth;
 }
 
-// ---- 4-wide -> 8-wide compressed nodes (bvh_build.h) ----------------------------------------------------------------------------
-namespace {
-struct Child8 { bool leaf; int32_t link; Box box; };
-inline uint32_t bf16_up(float x)          // the smallest bf16 >= x (x > 0), as its 16 high bits
-{
-    uint32_t b; std::memcpy(&b, &x, 4);
-    uint32_t h = b >> 16;
-    if ((h << 16) < b) h++;
-    return h;
-}
-inline float bf16_val(uint32_t h) { uint32_t b = h << 16; float f; std::memcpy(&f, &b, 4); return f; }
-}  // namespace
-
-bool widen_bvh8(const float* nodes4, int32_t n4, const int32_t* order4, const float* verts, int32_t ntri, float pad,
-                std::vector<uint32_t>& nodes8, std::vector<int32_t>& order8, int32_t& depth8)
-{
-    nodes8.clear(); order8.clear(); depth8 = 0;
-    if (n4 <= 0 || ntri <= 0) return false;
-    auto link_of = [&](int32_t i, int k) { int32_t l; std::memcpy(&l, nodes4 + (size_t)i * 16 + 6 + k, 4); return l; };
-    auto valid = [&](int32_t i, int k) {
-        uint32_t lo, hi; std::memcpy(&lo, nodes4 + (size_t)i * 16 + 10, 4); std::memcpy(&hi, nodes4 + (size_t)i * 16 + 13, 4);
-        return ((lo >> (8 * k)) & 255u) <= ((hi >> (8 * k)) & 255u);
-    };
-    // true padded boxes: triangles in leaf order, then the nodes bottom-up (links point forward in both builders' numbering)
-    std::vector<Box> tbox((size_t)ntri);
-    for (int32_t k = 0; k < ntri; k++)
-    {
-        const float* p = verts + (size_t)order4[k] * 9;
-        Box b; b.reset(); b.grow(p); b.grow(p + 3); b.grow(p + 6);
-        for (int a = 0; a < 3; a++) { b.mn[a] -= pad; b.mx[a] += pad; }
-        tbox[(size_t)k] = b;
-    }
-    std::vector<Box> cbox((size_t)n4 * 4), nbox((size_t)n4);
-    for (int32_t i = n4 - 1; i >= 0; i--)
-    {
-        Box u; u.reset();
-        for (int k = 0; k < 4; k++)
-        {
-            Box& c = cbox[(size_t)i * 4 + k]; c.reset();
-            if (!valid(i, k)) continue;
-            const int32_t l = link_of(i, k);
-            if (l >= 0) { if (l <= i || l >= n4) return false; c = nbox[(size_t)l]; }
-            else
-            {
-                const int32_t code = ~l, first = code >> 3, cnt = (code & 7) + 1;
-                if (first < 0 || first + cnt > ntri) return false;
-                for (int32_t t = first; t < first + cnt; t++) c.grow(tbox[(size_t)t]);
-            }
-            u.grow(c);
-        }
-        nbox[(size_t)i] = u;
-    }
-    auto kids = [&](int32_t i, std::vector<Child8>& out) {
-        for (int k = 0; k < 4; k++)
-            if (valid(i, k)) { const int32_t l = link_of(i, k); out.push_back({ l < 0, l, cbox[(size_t)i * 4 + k] }); }
-    };
-    auto count_kids = [&](int32_t i) { int c = 0; for (int k = 0; k < 4; k++) c += valid(i, k) ? 1 : 0; return c; };
-    struct Item { int32_t seed; int32_t depth; };
-    std::vector<Item> queue; queue.push_back({ 0, 1 });
-    int32_t next_index = 1;
-    order8.reserve((size_t)ntri);
-    std::vector<Child8> ch, tmp;
-    for (size_t qi = 0; qi < queue.size(); qi++)
-    {
-        const Item it = queue[qi];
-        depth8 = std::max(depth8, it.depth);
-        ch.clear(); kids(it.seed, ch);
-        for (;;)
-        {
-            if (ch.size() >= 8) break;
-            int n_int = 0; for (const Child8& c : ch) n_int += c.leaf ? 0 : 1;
-            int best = -1; float best_a = -1.0f;
-            for (size_t j = 0; j < ch.size(); j++)
-            {
-                if (ch[j].leaf) continue;
-                const int kc = count_kids(ch[j].link);
-                if (ch.size() - 1 + (size_t)kc > 8) continue;
-                // at most SEVEN interior children per node (the walk packs a group of pending children into 32 bits)
-                int gi = 0; for (int k = 0; k < 4; k++) if (valid(ch[j].link, k) && link_of(ch[j].link, k) >= 0) gi++;
-                if (n_int - 1 + gi > 7) continue;
-                const float a = ch[j].box.half_area();
-                if (a > best_a) { best_a = a; best = (int)j; }
-            }
-            if (best < 0) break;
-            const int32_t l = ch[(size_t)best].link;
-            ch.erase(ch.begin() + best);
-            kids(l, ch);
-        }
-        {   // a seed with more than seven interior children cannot occur (a 4-wide node has four); eight children all interior cannot either
-            int n_int = 0; for (const Child8& c : ch) n_int += c.leaf ? 0 : 1;
-            if (n_int > 7 || ch.size() > 8) return false;
-        }
-        Box u; u.reset();
-        for (const Child8& c : ch) u.grow(c.box);
-        int axis = 0;
-        { const float e0 = u.mx[0] - u.mn[0], e1 = u.mx[1] - u.mn[1], e2 = u.mx[2] - u.mn[2]; if (e1 > e0 && e1 >= e2) axis = 1; else if (e2 > e0 && e2 > e1) axis = 2; }
-        // interior children first, each part sorted along the node's longest axis (the walk visits interior children in slot order or
-        // reverse by the ray's sign on that axis)
-        std::stable_sort(ch.begin(), ch.end(), [&](const Child8& a, const Child8& b) {
-            if (a.leaf != b.leaf) return !a.leaf;
-            return a.box.mn[axis] + a.box.mx[axis] < b.box.mn[axis] + b.box.mx[axis];
-        });
-        uint32_t sc[3]; float scf[3];
-        for (int a = 0; a < 3; a++)
-        {
-            const double ext = (double)u.mx[a] - (double)u.mn[a];
-            float s = (float)(ext / 255.0 * (1.0 + 1e-6));
-            if (!(s > 1e-30f)) s = 1e-30f;
-            uint32_t h = bf16_up(s);
-            while ((double)u.mn[a] + 255.0 * (double)bf16_val(h) < (double)u.mx[a]) h++;
-            sc[a] = h; scf[a] = bf16_val(h);
-        }
-        uint32_t lo[3][2] = { { 0xffffffffu, 0xffffffffu }, { 0xffffffffu, 0xffffffffu }, { 0xffffffffu, 0xffffffffu } }, hi[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } };
-        uint32_t ni = 0, cnt16 = 0;
-        const uint32_t child_base = (uint32_t)next_index, tri_base = (uint32_t)order8.size();
-        for (size_t sidx = 0; sidx < ch.size(); sidx++)
-        {
-            const Child8& c = ch[sidx];
-            for (int a = 0; a < 3; a++)
-            {
-                const double o = u.mn[a], q = scf[a];
-                int ql = (int)std::floor(((double)c.box.mn[a] - o) / q), qh = (int)std::ceil(((double)c.box.mx[a] - o) / q);
-                ql = std::min(std::max(ql, 0), 255); qh = std::min(std::max(qh, 0), 255);
-                while (ql > 0 && o + ql * q > (double)c.box.mn[a]) ql--;
-                while (qh < 255 && o + qh * q < (double)c.box.mx[a]) qh++;
-                const int w = (int)sidx >> 2, sh = 8 * ((int)sidx & 3);
-                lo[a][w] = (lo[a][w] & ~(255u << sh)) | ((uint32_t)ql << sh);
-                hi[a][w] = (hi[a][w] & ~(255u << sh)) | ((uint32_t)qh << sh);
-            }
-            if (!c.leaf) { ni++; queue.push_back({ c.link, it.depth + 1 }); next_index++; }
-            else
-            {
-                const int32_t code = ~c.link, first = code >> 3, cnt = (code & 7) + 1;
-                if (cnt > 4) return false;                              // two bits per leaf
-                const uint32_t lr = (uint32_t)sidx - ni;
-                cnt16 |= (uint32_t)(cnt - 1) << (2 * lr);
-                for (int32_t t = first; t < first + cnt; t++) order8.push_back(order4[t]);
-            }
-        }
-        uint32_t w[20];
-        std::memcpy(&w[0], &u.mn[0], 4); std::memcpy(&w[1], &u.mn[1], 4); std::memcpy(&w[2], &u.mn[2], 4);
-        w[3] = sc[0] | (sc[1] << 16);
-        w[4] = sc[2] | (ni << 16) | ((uint32_t)axis << 24);
-        w[5] = child_base; w[6] = tri_base; w[7] = cnt16;
-        for (int a = 0; a < 3; a++) { w[8 + 2 * a] = lo[a][0]; w[9 + 2 * a] = lo[a][1]; w[14 + 2 * a] = hi[a][0]; w[15 + 2 * a] = hi[a][1]; }
-        nodes8.insert(nodes8.end(), w, w + 20);
-    }
-    if ((int64_t)order8.size() != (int64_t)ntri) return false;
-    if (next_index >= (1 << 24)) return false;                           // the walk packs a node index into 24 bits of a group word
-    return true;
-}
-
 }  // namespace ptk

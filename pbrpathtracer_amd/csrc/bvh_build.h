@@ -26,15 +26,6 @@ struct BuiltBvh {
 // leaf_max: 1..8 triangles per leaf.  Returns false if the stack bound cannot be met.
 bool build_bvh(const float* verts, int32_t n, int max_depth, int leaf_max, BuiltBvh& out);
 
-// The 4-wide tree of either builder widened to 8-wide COMPRESSED nodes, 80 bytes each (ptk_device.h NODE8): children absorbed
-// largest-surface-first until a node holds eight (at most seven of them interior), interior children first and consecutive in
-// memory (breadth-first numbering), the triangles of a node's leaf children contiguous in leaf order, child boxes re-quantised
-// OUTWARD from the TRUE padded boxes (recomputed bottom-up from the vertices) on the node's own grid with bf16 scales.
-// nodes4: n4 x 16 floats, order4: leaf order of the 4-wide tree; out: nodes8 = n8 x 20 dwords, order8, depth8 = nodes on the
-// longest root-to-leaf chain (what the traversal stack must hold).  Closest hits do not depend on the tree.
-bool widen_bvh8(const float* nodes4, int32_t n4, const int32_t* order4, const float* verts, int32_t ntri, float pad,
-                std::vector<uint32_t>& nodes8, std::vector<int32_t>& order8, int32_t& depth8);
-
 // Builder tuning of both builders (ptk_set_option "bvh_leaf_max", "bvh_trav_cost", "bvh_verbose"): 0 = the builders' own
 // choices.  They shape the tree, never a result (closest hits do not depend on the tree).
 struct BvhTuning { int leaf_max = 0; float trav_cost = 0.0f; int verbose = 0; };
