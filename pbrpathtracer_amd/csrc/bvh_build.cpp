@@ -16,7 +16,10 @@ namespace {
 
 constexpr int32_t NODE_EXIT_CODE = INT32_MIN;     // = NODE_EXIT of ptk_device.h: a link the walk never follows
 
-constexpr int kBins = 16;
+#ifndef PTK_BVH_BINS
+#define PTK_BVH_BINS 16
+#endif
+constexpr int kBins = PTK_BVH_BINS;
 float kTravCost = 1.0f;             // one node record = two slab tests (ptk_set_option "bvh_trav_cost" overrides, experiments)
 constexpr float kTriCost = 1.0f;
 

@@ -28,7 +28,10 @@
 namespace ptk {
 namespace {
 
-constexpr int kBins = 16;
+#ifndef PTK_BVH_BINS
+#define PTK_BVH_BINS 16
+#endif
+constexpr int kBins = PTK_BVH_BINS;
 constexpr int kHistWords = 3 * kBins * 7;            // per node: [axis][bin] { count, enc(mn.xyz), enc(mx.xyz) }
 constexpr int kThreads = 256;
 
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void level_bin_kernel(const float4* __res
 // few hundred histogram words with global atomics (measured on the 1 M-triangle scene: 46 ms for level 1, 29 ms for level 2,
 // ... 118 of the build's 134 ms in the first eight levels): every workgroup bins its share of the triangles into a private
 // copy of the level's histograms in LDS and then merges the bins it filled into the global ones.
-constexpr int kLdsLevelNodes = 96;                    // 96 x 1344 B = 126 KiB of the CU's 160 KiB
+constexpr int kLdsLevelNodes = 96 * 16 / kBins;        // 96 x 1344 B = 126 KiB of the CU's 160 KiB (16 bins)
 __global__ __launch_bounds__(1024) void level_bin_lds_kernel(const float4* __restrict__ boxes, int32_t* __restrict__ node_of, const BNode* __restrict__ nodes,
                                                              uint32_t* __restrict__ hist, int n, int lvl_start, int lvl_count, int level)
 {
