@@ -225,6 +225,9 @@ int ptk_gather_accum(ptk_ctx* ctx, void* rccl_comm, int root);
 int ptk_gather_wait(ptk_ctx* ctx);                                    /* host waits for the last exchange */
 int ptk_read_gathered(ptk_ctx* ctx, float* host_out);                 /* root: W*H*3 floats, rows bottom-up; waits */
 int ptk_gathered_device_ptr(ptk_ctx* ctx, void** dev_ptr, size_t* bytes);
+/* test hook: keeps the exchange stream busy for `milliseconds` (0 .. 10 000) ahead of whatever is queued on it next, so that the
+ * bound of ptk_gather_wait ("comm_timeout_s") can be exercised on one GPU; the kernel behind it always ends by itself */
+int ptk_debug_stall_exchange(ptk_ctx* ctx, int milliseconds);
 /* parity probes of the pack / unpack kernels: one GPU can play every rank of a split */
 int ptk_probe_pack(ptk_ctx* ctx, int rank, int world, float* host_out /* [ptk_packed_floats] */);
 int ptk_probe_unpack(ptk_ctx* ctx, int world, const float* host_packed /* all ranks, back to back */, float* host_image);

@@ -1459,13 +1459,42 @@ int ptk_gather_wait(ptk_ctx* c)
                           async != ncclSuccess && async != ncclInProgress ? "failed" : "timed out", waited,
                           c->rank == c->gather_root ? "still expecting" : "still sending", c->gather_bytes,
                           async != ncclSuccess && async != ncclInProgress ? (std::string(" - RCCL: ") + ncclGetErrorString(async)).c_str() : " - a rank never joined this step");
-            if (c->comm) { (void)ncclCommAbort(c->comm); c->comm = nullptr; }
+            if (c->comm)
+            {
+                // the abort releases RCCL's own kernels, but it also waits for whatever else sits on the stream: it runs on a helper
+                // thread and this call gives it one more timeout's worth (at most 5 s) before it returns regardless
+                ncclComm_t doomed = c->comm;
+                c->comm = nullptr;
+                auto done = std::make_shared<std::atomic<bool>>(false);
+                std::thread([doomed, done] { (void)ncclCommAbort(doomed); done->store(true); }).detach();
+                const auto a0 = std::chrono::steady_clock::now();
+                const double grace = std::min(c->opt_comm_timeout_s, 5.0);
+                while (!done->load() && std::chrono::duration<double>(std::chrono::steady_clock::now() - a0).count() < grace)
+                    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
             c->gather_pending = false;
             return fail(c, PTK_ERR_RCCL, msg);
         }
         if (waited > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
     c->gather_pending = false;
+    return PTK_OK;
+}
+
+// Test hook of the bounded waits: one lane that keeps the exchange stream busy for a fixed time (wall clock, 100 MHz), so that
+// a single GPU can show what ptk_gather_wait does when an exchange step does not complete in time.  It always ends by itself.
+__global__ void stall_kernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+int ptk_debug_stall_exchange(ptk_ctx* c, int milliseconds)
+{
+    if (!c || milliseconds < 0 || milliseconds > 10000) return PTK_ERR_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    stall_kernel<<<1, 1, 0, c->xstream>>>((unsigned long long)milliseconds * 100000ull);
+    HIPCHK(c, hipGetLastError());
     return PTK_OK;
 }
 

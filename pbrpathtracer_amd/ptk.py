@@ -71,6 +71,7 @@ SYMBOLS = [
     "ptk_packed_floats", "ptk_packed_layout", "ptk_comm_unique_id", "ptk_comm_init", "ptk_comm_destroy",
     "ptk_gather_wait", "ptk_read_gathered", "ptk_gathered_device_ptr", "ptk_probe_pack", "ptk_probe_unpack",
     "ptk_bind_out_image", "ptk_bind_out_device", "ptk_bind_gl_buffer", "ptk_comm_info", "ptk_kernel_log", "ptk_kernel_log_read",
+    "ptk_debug_stall_exchange",
 ]
 
 
@@ -140,6 +141,7 @@ def _load_locked() -> C.CDLL:
     try:
         L.ptk_kernel_log.argtypes = [vp, i32]
         L.ptk_kernel_log_read.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]
+        L.ptk_debug_stall_exchange.argtypes = [vp, i32]
     except AttributeError:
         if LIB_PATH.endswith("libptk.so"):      # (an older build loaded through PTK_DEV_TOOLS for an A/B may lack the newest entry points)
             raise
@@ -364,6 +366,9 @@ class Context:
 
     def gather_accum(self, root: int = 0, comm=None):
         self._chk(self.L.ptk_gather_accum(self.h, comm, root), "ptk_gather_accum")
+
+    def debug_stall_exchange(self, milliseconds: int):
+        self._chk(self.L.ptk_debug_stall_exchange(self.h, int(milliseconds)), "ptk_debug_stall_exchange")
 
     def gather_wait(self):
         self._chk(self.L.ptk_gather_wait(self.h), "ptk_gather_wait")

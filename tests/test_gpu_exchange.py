@@ -166,6 +166,47 @@ def test_native_gather_wait_is_bounded():
     assert "REFUSED" in r.stdout and "rank 0 of 2" in r.stdout and "waited" in r.stdout, (r.stdout, r.stderr[-2000:])
 
 
+def test_native_gather_wait_times_out_on_a_step_that_does_not_complete():
+    """The bound INSIDE ptk_gather_wait, on one GPU: the exchange stream is kept busy for 3 s (ptk_debug_stall_exchange) ahead of an
+    exchange step, and comm_timeout_s is 0.3 s - the wait must come back with PTK_ERR_RCCL naming step, rank, root and the bytes
+    outstanding well before the stream drains, the communicator is gone afterwards (aborted), and a fresh one gathers the right
+    image again.  In a child process under a time limit: a wait that is not bounded would otherwise hang the suite."""
+    code = (
+        "import sys, time; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from pbrpathtracer_amd import ptk\n"
+        "from test_gpu_exchange import _ctx\n"
+        "c = _ctx(); c.comm_init(ptk.comm_unique_id(), 0, 1)\n"
+        "c.reset(); c.render(0, 4, 11)\n"
+        "c.gather_accum(0); c.gather_wait(); c.synchronize()\n"        # step 1: allocates the exchange buffers (which synchronises)
+        "c.set_option('comm_timeout_s', 0.3)\n"
+        "c.debug_stall_exchange(3000)\n"
+        "c.gather_accum(0)\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        "    c.gather_wait(); print('WAITED %%.2f s' %% (time.time() - t0))\n"
+        "except ptk.PtkError as e:\n"
+        "    print('REFUSED in %%.2f s: %%s' %% (time.time() - t0, e))\n"
+        "try:\n"
+        "    c.gather_accum(0); print('GATHERED WITHOUT A COMMUNICATOR')\n"
+        "except ptk.PtkError as e:\n"
+        "    print('AFTERWARDS: %%s' %% e)\n"
+        "c.synchronize()\n"
+        "c.set_option('comm_timeout_s', 60)\n"
+        "c.comm_init(ptk.comm_unique_id(), 0, 1)\n"
+        "c.gather_accum(0); g = c.read_gathered()\n"
+        "print('RECOVERED' if np.array_equal(g, c.read_accum()) else 'WRONG IMAGE AFTER RECOVERY')\n"
+        "sys.stdout.flush()\n"
+        "import os; os._exit(0)\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    out = r.stdout
+    assert "REFUSED in" in out and "timed out" in out and "step 2 on rank 0 of 1 (root 0)" in out and "still expecting" in out, (out, r.stderr[-2000:])
+    waited = float(out.split("REFUSED in ")[1].split(" s")[0])
+    assert 0.3 <= waited < 1.5, out
+    assert "AFTERWARDS:" in out and "communicator" in out.split("AFTERWARDS:")[1].splitlines()[0], out
+    assert "RECOVERED" in out, (out, r.stderr[-2000:])
+
+
 def test_native_gather_between_two_gpus(tmp_path):
     """The N > 1 branch of ptk_gather_accum (grouped ncclSend / ncclRecv on the library's own communicator, exchange
     stream next to persistent trace waves) with two real ranks: two fresh child processes, one GPU each, render their
